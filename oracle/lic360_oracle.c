@@ -1,0 +1,640 @@
+/* lic360_oracle.c -- CPU ORACLE for the LIC360 hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the reference's CUDA kernels and C++ coder,
+ * function by function, each citing the reference file:line it follows (paths are
+ * relative to /root/reference).  It is the checker for the HIP product path: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product (360-image-compression_amd/) never links, imports or calls anything here.
+ *
+ * Pinning status:
+ *   - arithmetic coder + bit I/O: PINNED against the reference's own
+ *     extension/ArithmeticCoder.cpp + extension/BitIoStream.cpp compiled from where
+ *     they lie into oracle/_ref/ (see oracle/Makefile) and against the committed
+ *     fixtures tests/golden/ac_*.npz produced by oracle/gen_golden.py.
+ *   - index/copy kernels (sphere, dtow, tile, context, imp_map, ...): pinned by
+ *     independent numpy/torch-CPU restatements in tests/.
+ *   - masked convolution: pinned to F.conv2d with the mask_constrain rule to 1e-4
+ *     (summation order differs); the evaluation ORDER follows cconv_ec_cuda.cu
+ *     literally with fmaf as the canonical multiply-add.
+ *   - exp/erf/log: "parity unpinned" at the last ulp versus CUDA libdevice (no CUDA
+ *     device or golden vector exists); the contract is csrc/lic360_exact_math.h,
+ *     shared verbatim with the HIP kernels, checked against float64 scipy in tests/.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "../360-image-compression_amd/csrc/lic360_exact_math.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------
+ * A8  code_contex_opt::reshape           extension/code_contex_cuda.cu:11-32
+ * idx[k]=ph, idx[k+HW]=pw in anti-diagonal scan order; plane_idx[pn] prefix, H+W entries.
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_code_contex(int H, int W, int *idx, int *plane_idx) {
+    int stride = H * W;
+    int pidx = 0, pn = 0;
+    for (; pn < H + W - 1; pn++) {
+        plane_idx[pn] = pidx;
+        int ph = pn >= W ? pn - W + 1 : 0;
+        for (; ph < H; ph++) {
+            int pw = pn - ph;
+            if (pw < 0) break;
+            idx[pidx] = ph;
+            idx[pidx + stride] = pw;
+            pidx += 1;
+        }
+    }
+    plane_idx[pn] = pidx;
+}
+
+/* plane window [la, lb] used by every plane-stepped op, e.g. cconv_dc_cuda.cu:374-376 */
+static void plane_window(int psum, int G, int H, int W, const int *plane_idx, int *start, int *len) {
+    int la = psum >= G ? psum - G + 1 : 0;
+    int lb = psum > H + W - 2 ? H + W - 2 : psum;
+    *start = plane_idx[la];
+    *len = plane_idx[lb + 1] - plane_idx[la];
+    if (*len < 0) *len = 0;
+}
+ORC_API int orc_plane_len(int psum, int G, int H, int W, const int *plane_idx) {
+    int s, l;
+    if (psum < 0 || psum >= H + W + G - 2) return 0;
+    plane_window(psum, G, H, W, plane_idx, &s, &l);
+    return l;
+}
+
+/* ------------------------------------------------------------------------------------
+ * A9/A10 one output scalar of the masked convolution.
+ * Literal restatement of cconv_ec_act_forward_kernel_batch, extension/cconv_ec_cuda.cu:268-315
+ * (identical body in cconv_dc_cuda.cu:313-364): 128 virtual lanes, lane `tid` walks flat
+ * indices tid, tid+128, ... < 25*cin, accumulating ONE running sum; then the fixed tree
+ * p[i]+p[i+64]; +32; then shfl_down 16,8,4,2,1 inside a 32-wide warp (:299-309).
+ * `sum = sum + x*w` is ONE fmaf.
+ * ---------------------------------------------------------------------------------- */
+static float conv_one(const float *input, const float *weight, int n, int o_global, int o_local,
+                      int th, int tw, int C, int H, int W, int ksz, int group_in, int group_out,
+                      int constrain) {
+    const int blockSize = 128;
+    float p[128];
+    int inner = H * W, skernel = ksz * ksz, half = ksz / 2;
+    int nblock = skernel * group_in;
+    int tc = o_local / group_out;
+    int psum = th + tw + tc;
+    for (int tid = 0; tid < blockSize; ++tid) {
+        float sum = 0.0f;
+        for (int index = tid; index < nblock; index += blockSize) {
+            int kw = index % ksz, kh = (index / ksz) % ksz, gid = index / ksz / ksz;
+            int ph = th - half + kh, pw = tw - half + kw;
+            if (ph >= H || ph < 0 || pw >= W || pw < 0) continue;
+            int nchannel = constrain == 5 ? (psum - ph - pw) * group_in : (psum - ph - pw + 1) * group_in;
+            if (nchannel > C) nchannel = C;
+            if (nchannel > 0) {
+                long wbase = ((long)o_global * C * ksz + kh) * ksz + kw;
+                long dbase = ((long)n * C * H + ph) * W + pw;
+                for (int ti = gid; ti < nchannel; ti += group_in)
+                    sum = __builtin_fmaf(input[dbase + (long)ti * inner], weight[wbase + (long)ti * skernel], sum);
+            }
+        }
+        p[tid] = sum;
+    }
+    for (int i = 0; i < 64; ++i) p[i] = p[i] + p[i + 64];
+    for (int i = 0; i < 32; ++i) p[i] = p[i] + p[i + 32];
+    for (int off = 16; off > 0; off >>= 1)
+        for (int i = 0; i < off; ++i) p[i] = p[i] + p[i + off];
+    return p[0];
+}
+
+/* EC: whole tensor.  nb = number of stacked nets (weight.size(0) in the *_batch forwards,
+ * 1 otherwise); input [N,C,H,W] with N % nb == 0; weight [nb,nout,C,k,k]; bias/act [nb,nout].
+ * act == NULL -> no PReLU.  EC PReLU: sum>0 ? sum : sum*a  (cconv_ec_cuda.cu:311-312). */
+ORC_API void orc_cconv_ec(const float *input, const float *weight, const float *bias, const float *act,
+                          float *output, int N, int C, int H, int W, int nout, int ngroup, int ksz,
+                          int constrain, int nb) {
+    int group_in = C / ngroup, group_out = nout / ngroup, npb = N / nb;
+    long total = (long)N * nout * H * W;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long b = 0; b < total; ++b) {
+        int pos = (int)(b % (H * W));
+        int o = (int)((b / (H * W)) % nout);
+        int n = (int)(b / ((long)H * W * nout));
+        int nbatch = n / npb;
+        int bid = nbatch * nout + o;
+        float s = conv_one(input, weight, n, bid, o, pos / W, pos % W, C, H, W, ksz, group_in, group_out, constrain);
+        s = s + bias[bid];
+        if (act) s = s > 0 ? s : s * act[bid];
+        output[b] = s;
+    }
+}
+
+/* DC: one plane `psum` (cconv_dc_cuda.cu:367-398).  Writes only the plane's outputs into the
+ * persistent `output` [N,nout,H,W]; zero-fills it at psum==0 (:385).  DC PReLU: if(sum<0)
+ * sum*=a (:360-362). */
+ORC_API void orc_cconv_dc_plane(const float *input, const float *weight, const float *bias, const float *act,
+                                float *output, int N, int C, int H, int W, int nout, int ngroup, int ksz,
+                                int constrain, int nb, const int *idx, const int *plane_idx, int psum) {
+    int group_in = C / ngroup, group_out = nout / ngroup, npb = N / nb;
+    int mod = H + W + ngroup - 2, start, len;
+    if (psum >= mod) return;
+    plane_window(psum, ngroup, H, W, plane_idx, &start, &len);
+    if (len <= 0) return;
+    if (psum == 0) memset(output, 0, sizeof(float) * (size_t)N * nout * H * W);
+    long total = (long)N * group_out * len;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long b = 0; b < total; ++b) {
+        int a = (int)(b % len), og = (int)((b / len) % group_out), n = (int)(b / ((long)len * group_out));
+        int th = idx[a + start], tw = idx[a + start + H * W];
+        int tc = psum - th - tw;
+        int pout = tc * group_out + og;
+        int nbatch = n / npb;
+        int bid = nbatch * nout + pout;
+        float s = conv_one(input, weight, n, bid, pout, th, tw, C, H, W, ksz, group_in, group_out, constrain);
+        s = s + bias[bid];
+        if (act) { if (s < 0) s = s * act[bid]; }
+        output[(((long)n * nout + pout) * H + th) * W + tw] = s;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A11 tile_extract                         extension/tile_extract_cuda.cu:31-45,48-98
+ * label mode: gather plane psum into out[N][len][cpn]; returns len*N (the CPU count tensor).
+ * non-label mode (:79-93): psum==0 zero-fills, else gathers plane psum-1.
+ * ---------------------------------------------------------------------------------- */
+static void tile_gather(const float *in, float *out, int N, int C, int H, int W, int cpn,
+                        const int *idx, int start, int len, int psum) {
+    long num = (long)N * cpn * len;
+    for (long i = 0; i < num; ++i) {
+        int ci = (int)(i % cpn), tl = (int)((i / cpn) % len), tn = (int)(i / cpn / len);
+        int th = idx[tl + start], tw = idx[tl + start + H * W];
+        int tc = psum - tw - th;
+        out[i] = in[(((long)tn * C + tc * cpn + ci) * H + th) * W + tw];
+    }
+}
+ORC_API int orc_tile_extract(const float *in, float *out, int N, int C, int H, int W, int ngroup, int label,
+                             const int *idx, const int *plane_idx, int psum) {
+    int cpn = C / ngroup, mod = H + W + ngroup - 2, start, len;
+    if (label) {
+        if (psum >= mod) return 0;
+        plane_window(psum, ngroup, H, W, plane_idx, &start, &len);
+        if (len > 0) tile_gather(in, out, N, C, H, W, cpn, idx, start, len, psum);
+        return N * len;
+    }
+    if (psum == 0) { memset(out, 0, sizeof(float) * (size_t)N * cpn * H * W); return 0; }
+    if (psum <= mod) {
+        psum -= 1;
+        plane_window(psum, ngroup, H, W, plane_idx, &start, &len);
+        if (len > 0) tile_gather(in, out, N, C, H, W, cpn, idx, start, len, psum);
+        return N * len;
+    }
+    return 0;
+}
+/* batch variant (:101-151): N = 3*nout stacked nets; slab pn placed at pn*cpn*H*W*nout. */
+ORC_API int orc_tile_extract_batch(const float *in, float *out, int N, int C, int H, int W, int ngroup,
+                                   const int *idx, const int *plane_idx, int psum) {
+    int cpn = C / ngroup, mod = H + W + ngroup - 2, start, len, nout = N / 3;
+    if (psum >= mod) return 0;
+    plane_window(psum, ngroup, H, W, plane_idx, &start, &len);
+    long num = (long)N * cpn * len;
+    long stride = (long)cpn * H * W * nout, inner = (long)len * cpn * nout;
+    for (long i = 0; i < num; ++i) {
+        long ps = i % inner, pn = i / inner;
+        int ci = (int)(i % cpn), tl = (int)((i / cpn) % len), tn = (int)(i / cpn / len);
+        int th = idx[tl + start], tw = idx[tl + start + H * W];
+        int tc = psum - tw - th;
+        out[pn * stride + ps] = in[(((long)tn * C + tc * cpn + ci) * H + th) * W + tw];
+    }
+    return nout * len;
+}
+
+/* A12 tile_input                            extension/tile_input_cuda.cu:27-76
+ * in: compact [N][len] symbols of plane psum-1; out [rep*N, G, H, W]. */
+ORC_API void orc_tile_input(const float *in, float *out, int N, int G, int H, int W, float bias, float scale,
+                            int rep, const int *idx, const int *plane_idx, int psum) {
+    long stride_out = (long)N * G * H * W;
+    int mod = H + W + G - 2, start, len;
+    if (psum == 0) { memset(out, 0, sizeof(float) * (size_t)rep * stride_out); return; }
+    if (psum > mod) return;
+    psum -= 1;
+    plane_window(psum, G, H, W, plane_idx, &start, &len);
+    long count = (long)N * len;
+    for (long i = 0; i < count; ++i) {
+        int tl = (int)(i % len), tn = (int)(i / len);
+        int th = idx[tl + start], tw = idx[tl + start + H * W];
+        int tc = psum - tw - th;
+        long pidx = (((long)tn * G + tc) * H + th) * W + tw;
+        float tmp = lic360_affine(in[i], scale, bias);
+        for (int j = 0; j < rep; ++j) out[pidx + j * stride_out] = tmp;
+    }
+}
+
+/* A13 tile_add                              extension/tile_add_cuda.cu:22-60 (in place y += x on plane) */
+ORC_API void orc_tile_add(float *y, const float *x, int N, int C, int H, int W, int ngroup,
+                          const int *idx, const int *plane_idx, int psum) {
+    int cpg = C / ngroup, start, len;
+    if (psum >= H + W + ngroup - 2) return;
+    plane_window(psum, ngroup, H, W, plane_idx, &start, &len);
+    long count = (long)N * cpg * len;
+    for (long i = 0; i < count; ++i) {
+        int pn = (int)(i % N);
+        long pp = i / N;
+        int pb = (int)(pp % len), og = (int)(pp / len);
+        int th = idx[pb + start], tw = idx[pb + start + H * W];
+        int tc = psum - th - tw;
+        long o = (((long)pn * C + tc * cpg + og) * H + th) * W + tw;
+        y[o] = y[o] + x[o];
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A14 entropy_gmm_table                     extension/entropy_gmm_table_cuda.cu:109-135,161-191
+ * Mutates weight/delta in place like the reference (:29-57).  out: float[tn][nstep+1].
+ * ---------------------------------------------------------------------------------- */
+static void gmm_rows(float *w, float *d, const float *m, float *out, int tn, int ng, int nstep,
+                     float bias, float total, float beta) {
+    for (int n = 0; n < tn; ++n) lic360_softmax_inplace(w + (long)n * ng, ng);
+    for (long i = 0; i < (long)tn * ng; ++i) d[i] = lic360_sigma_floor(d[i], beta);
+    int ntable = nstep + 1;
+    for (int n = 0; n < tn; ++n) {
+        float *T = out + (long)n * ntable;
+        T[0] = 0.0f;
+        T[ntable - 1] = (float)(int)total;
+        for (int pt = 1; pt < ntable - 1; ++pt)
+            T[pt] = (float)lic360_gmm_cdf_entry(pt, bias, total, w + (long)n * ng, d + (long)n * ng, m + (long)n * ng, ng);
+        lic360_cdf_fixup(T, nstep, 0);
+    }
+}
+ORC_API void orc_gmm_table(float *weight, float *delta, const float *mean, float *out, int tn, int ng,
+                           int nstep, float bias, float total, float beta) {
+    gmm_rows(weight, delta, mean, out, tn, ng, nstep, bias, total, beta);
+}
+/* batch layout: data = [w slab | sigma slab | mu slab], slab stride `stride` floats (:165,177-183) */
+ORC_API void orc_gmm_table_batch(float *data, long stride, float *out, int tn, int ng, int nstep,
+                                 float bias, float total, float beta) {
+    if (tn > 0) gmm_rows(data, data + stride, data + 2 * stride, out, tn, ng, nstep, bias, total, beta);
+}
+
+/* A15 entropy_table                         extension/entropy_table_cuda.cu:24-96 */
+ORC_API void orc_entropy_table(const float *data, float *out, int count, int nstep, float total) {
+    float tmp[64];
+    for (int n = 0; n < count; ++n) {
+        float *T = out + (long)n * (nstep + 1);
+        lic360_softmax_cdf(data + (long)n * nstep, T, tmp, nstep, total);
+        lic360_cdf_fixup(T, nstep, 1);
+    }
+}
+
+/* A16 entropy_gmm forward (+ analytic grads) extension/entropy_gmm_cuda.cu:36-68 */
+ORC_API void orc_entropy_gmm(const float *weight, const float *delta, const float *mean, const float *label,
+                             float *loss, float *wd, float *dd, float *md, float *ld, int M, int ng) {
+    const float s2 = 0x1.6a09e6p-1f;             /* float(1/sqrt(2)) */
+    const float sp2 = 0x1.988454p-2f;            /* float(1/sqrt(2*pi)) */
+    for (int n = 0; n < M; ++n) {
+        float sum_p = 0.0f;
+        ld[n] = 0.0f;
+        for (int i = 0; i < ng; ++i) {
+            long k = (long)n * ng + i;
+            float xa = (float)((double)label[n] - 0.5 - (double)mean[k]);
+            float xb = (float)((double)label[n] + 0.5 - (double)mean[k]);
+            float id = (float)(1.0 / (double)delta[k]);
+            float fa = (float)(0.5 + 0.5 * (double)lic360_erff(xa * id * s2));
+            float fb = (float)(0.5 + 0.5 * (double)lic360_erff(xb * id * s2));
+            float p = fb - fa;
+            sum_p = __builtin_fmaf(weight[k], p, sum_p);
+            float ga = sp2 * id * lic360_expf((float)(-0.5 * (double)xa * (double)xa * (double)id * (double)id));
+            float gb = sp2 * id * lic360_expf((float)(-0.5 * (double)xb * (double)xb * (double)id * (double)id));
+            ld[n] += (gb - ga) * weight[k];
+            dd[k] = id * (-xb * gb + xa * ga) * weight[k];
+            md[k] = (ga - gb) * weight[k];
+            wd[k] = p;
+        }
+        loss[n] = -lic360_logf((float)((double)sum_p + 0.0000001));
+        float ip = (float)(-1.0 / ((double)sum_p + 0.0000001));
+        ld[n] *= ip;
+        for (int i = 0; i < ng; ++i) {
+            long k = (long)n * ng + i;
+            dd[k] *= ip; md[k] *= ip; wd[k] *= ip;
+        }
+    }
+}
+
+/* A17 context_reshape / contex_shift        extension/context_reshape_cuda.cu:30-39,
+ *                                           extension/contex_shift_cuda.cu:36-62 */
+ORC_API void orc_context_reshape(const float *in, float *out, int N, int C, int H, int W, int ngroup) {
+    int cpg = C / ngroup;
+    long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        long pn = i / inner / C, pc = (i / inner) % C, ps = i % inner;
+        long t = (pn * inner * C / cpg + pc / cpg * inner + ps) * cpg + pc % cpg;
+        out[t] = in[i];
+    }
+}
+/* inv==0: out[N,C,H+W+G-2,W] (zero-filled here; the reference leaves the rest uninitialised);
+ * inv!=0: in is the skewed tensor of height Hin, out height Hin-W-G+2. */
+ORC_API void orc_contex_shift(const float *in, float *out, int N, int C, int Hin, int W, int cpn, int inv) {
+    int G = C / cpn;
+    if (!inv) {
+        int Hout = Hin + W + G - 2;
+        memset(out, 0, sizeof(float) * (size_t)N * C * Hout * W);
+        long total = (long)N * C * Hin * W;
+        for (long i = 0; i < total; ++i) {
+            int w = (int)(i % W), h = (int)((i / W) % Hin), c = (int)((i / W / Hin) % C), n = (int)(i / W / Hin / C);
+            int ph = w + h + c / cpn;
+            out[(((long)n * C + c) * Hout + ph) * W + w] = in[i];
+        }
+    } else {
+        int Hout = Hin - W - G + 2;
+        long total = (long)N * C * Hout * W;
+        for (long i = 0; i < total; ++i) {
+            int w = (int)(i % W), h = (int)((i / W) % Hout), c = (int)((i / W / Hout) % C), n = (int)(i / W / Hout / C);
+            int ph = w + h + c / cpn;
+            out[i] = in[(((long)n * C + c) * Hin + ph) * W + w];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A1-A3 sphere ops
+ * ---------------------------------------------------------------------------------- */
+/* sphere_pad_forward_kernel                 extension/sphere_pad_cuda.cu:29-46 */
+ORC_API void orc_sphere_pad(const float *in, float *out, int NC, int H, int W, int pad) {
+    int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    long total = (long)NC * Ho * Wo;
+    for (long i = 0; i < total; ++i) {
+        int pw = (int)(i % Wo), ph = (int)((i / Wo) % Ho);
+        long pn = i / Wo / Ho;
+        int th = ph - pad, tw = pw - pad;
+        tw = (tw + W) % W;
+        if (th < 0 || th >= H) { th = (2 * H - 1 - th) % H; tw = (2 * W - 1 - tw) % W; }
+        out[i] = in[(pn * H + th) * W + tw];
+    }
+}
+/* sphere_pad_forward_kernel_inplace          extension/sphere_pad_cuda.cu:48-65; Hp,Wp padded dims */
+ORC_API void orc_sphere_pad_inplace(float *data, int NC, int Hp, int Wp, int pad) {
+    int H = Hp - 2 * pad, W = Wp - 2 * pad;
+    long total = (long)NC * Hp * Wp;
+    for (long i = 0; i < total; ++i) {
+        int pw = (int)(i % Wp), ph = (int)((i / Wp) % Hp);
+        if (pw >= pad && pw < pad + W && ph >= pad && ph < pad + H) continue;
+        long pn = i / Wp / Hp;
+        int th = ph - pad, tw = pw - pad;
+        tw = (tw + W) % W;
+        if (th < 0 || th >= H) { th = (2 * H - 1 - th) % H; tw = (2 * W - 1 - tw) % W; }
+        data[i] = data[(pn * Hp + th + pad) * Wp + tw + pad];
+    }
+}
+/* sphere_trim_kernel                         extension/sphere_trim_cuda.cu:17-26 */
+ORC_API void orc_sphere_trim(float *data, int NC, int H, int W, int pad) {
+    long total = (long)NC * H * W;
+    for (long i = 0; i < total; ++i) {
+        int pw = (int)(i % W), ph = (int)((i / W) % H);
+        if (ph < pad || ph >= H - pad || pw < pad || pw >= W - pad) data[i] = 0;
+    }
+}
+/* sphere_cut_edge_forward_kernel             extension/sphere_cut_edge_cuda.cu:31-41 */
+ORC_API void orc_sphere_cut_edge(const float *in, float *out, int NC, int H, int W, int pad) {
+    int Ho = H - 2 * pad, Wo = W - 2 * pad;
+    long total = (long)NC * Ho * Wo;
+    for (long i = 0; i < total; ++i) {
+        int pw = (int)(i % Wo), ph = (int)((i / Wo) % Ho);
+        long pn = i / Wo / Ho;
+        out[i] = in[(pn * H + ph + pad) * W + pw + pad];
+    }
+}
+/* sphere_lat_scale_forward_kernel            extension/sphere_lat_scale_cuda.cu:31-38 */
+ORC_API void orc_sphere_lat_scale(const float *in, const float *weight, float *out, int NC, int H, int W, int npart) {
+    int hp = H / npart;
+    long total = (long)NC * H * W;
+    for (long i = 0; i < total; ++i) {
+        int ph = (int)((i / W) % H) / hp;
+        out[i] = in[i] * weight[ph];
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A4 imp_map forward (+mask)                 extension/imp_map_cuda.cu:79-110
+ * A18 imp2mask, scale                        extension/imp2mask_cuda.cu:25-38, scale_cuda.cu:24-30
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_imp_map(const float *in, const float *imp, float *out, float *mask, int N, int C, int H, int W, int levels) {
+    int cpl = C / levels;
+    long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        long ps = i % inner, pc = (i / inner) % C, pn = i / inner / C;
+        int ch = (int)((double)(imp[pn * inner + ps] * (float)levels) + 0.00001) * cpl;
+        out[i] = pc < ch ? in[i] : 0.0f;
+        if (mask) mask[i] = pc < ch ? 1.0f : 0.0f;
+    }
+}
+/* init_alpha_constrain_kernel + host post-processing, extension/imp_map_cuda.cu:27-71:
+ * constrain[n,h] = rt*( |cos((0.5-(h+0.5)/H)*pi)| / max * sc + 1 - sc ).  fp32 steps as torch does them;
+ * the cos itself is libdevice cosf in the reference -> compared with 1e-6 tolerance only. */
+ORC_API void orc_imp_map_constrain(float *constrain, int N, int H, float rt, float sc) {
+    float pi = (float)acos(-1.0);
+    float mx = 0.0f;
+    float *a = (float *)malloc(sizeof(float) * H);
+    for (int h = 0; h < H; ++h) {
+        float v = (float)cos((double)(float)((0.5 - ((double)h + 0.5) / (double)H) * (double)pi));
+        a[h] = v < 0 ? -v : v;
+        if (a[h] > mx) mx = a[h];
+    }
+    for (int n = 0; n < N; ++n)
+        for (int h = 0; h < H; ++h) {
+            float t = a[h] / mx;
+            t = t * sc;
+            t = t + 1.0f;
+            t = t - sc;
+            constrain[n * H + h] = rt * t;
+        }
+    free(a);
+}
+ORC_API void orc_imp2mask(const float *in, float *out, int N, int C, int H, int W, int cpn) {
+    long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        long ps = i % inner, pc = (i / inner) % C, pn = i / inner / C;
+        int imp = (int)((double)in[pn * inner + ps] + 1e-5) * cpn;
+        out[i] = pc < imp ? 1.0f : 0.0f;
+    }
+}
+ORC_API void orc_scale(const float *in, float *out, long n, float bias, float scale) {
+    for (long i = 0; i < n; ++i) out[i] = lic360_affine(in[i], scale, bias);
+}
+
+/* ------------------------------------------------------------------------------------
+ * A5 quant forward                           extension/quant_cuda.cu:35-86,136-169
+ * weight_b [C,levels] -> centres increments; top = dequantised value, qidx = index as float,
+ * count[C,levels] += -1 per hit (atomicAdd(count,-1.0), :56,74).
+ * A7 dquant forward                          extension/dquant_cuda.cu:24-47
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_quant(const float *in, const float *weight_b, float *top, float *qidx, float *count,
+                       int N, int C, int H, int W, int levels) {
+    float *wq = (float *)malloc(sizeof(float) * C * levels);
+    for (int i = 0; i < C * levels; ++i) wq[i] = (i % levels == 0) ? weight_b[i] : lic360_expf(weight_b[i]);
+    memset(count, 0, sizeof(float) * C * levels);
+    long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        int pc = (int)((i / inner) % C);
+        float t;
+        int j = lic360_quant_one(in[i], wq + pc * levels, levels, &t);
+        top[i] = t;
+        if (qidx) qidx[i] = (float)j;
+        count[pc * levels + j] += -1.0f;
+    }
+    free(wq);
+}
+ORC_API void orc_dquant(const float *in, const float *mask, const float *weight_b, float *out,
+                        int N, int C, int H, int W, int levels) {
+    float *wc = (float *)malloc(sizeof(float) * C * levels);
+    for (int c = 0; c < C; ++c) {
+        wc[c * levels] = weight_b[c * levels];
+        for (int i = 1; i < levels; ++i) wc[c * levels + i] = wc[c * levels + i - 1] + lic360_expf(weight_b[c * levels + i]);
+    }
+    long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        int tc = (int)((i / inner) % C);
+        int id = (int)((double)in[i] + 0.00001);
+        out[i] = mask[i] > 0 ? wc[tc * levels + id] : wc[tc * levels];
+    }
+    free(wc);
+}
+
+/* A6 dtow / wtod                             extension/dtow_cuda.cu:38-75 */
+ORC_API void orc_dtow(const float *in, float *out, int N, int C, int H, int W, int s, int d2w) {
+    long total = (long)N * C * H * W;
+    int p2 = s * s;
+    int Co = d2w ? C / p2 : C * p2, Ho = d2w ? H * s : H / s, Wo = d2w ? W * s : W / s;
+    for (long i = 0; i < total; ++i) {
+        int tw = (int)(i % W), th = (int)((i / W) % H), tc = (int)((i / W / H) % C), tn = (int)(i / W / H / C);
+        int pc, ph, pw;
+        if (d2w) { pc = tc / p2; int rc = tc % p2; ph = th * s + rc / s; pw = tw * s + rc % s; }
+        else { ph = th / s; pw = tw / s; pc = tc * p2 + (th % s) * s + tw % s; }
+        out[(((long)tn * Co + pc) * Ho + ph) * Wo + pw] = in[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * A20 arithmetic coder + bit I/O              extension/ArithmeticCoder.cpp:15-170,
+ *                                             extension/BitIoStream.cpp:12-71
+ * Bit-by-bit restatement (STATE_SIZE = 32, extension/coder.h:20,34) on a memory buffer.
+ * ---------------------------------------------------------------------------------- */
+#define AC_MASK   0xFFFFFFFFull
+#define AC_TOP    0x80000000ull
+#define AC_SECOND 0x40000000ull
+#define AC_MINR   ((1ull << 30) + 2)
+#define AC_MAXR   (1ull << 32)
+
+typedef struct {
+    uint64_t low, high, code;
+    unsigned long underflow;
+    uint8_t *buf; size_t cap, len;       /* encoder output / decoder input */
+    int cur, nbits;                      /* BitOutputStream currentByte/numBitsFilled or input state */
+    size_t rpos; int eof;
+    int error;
+} orc_ac;
+
+static void bit_write(orc_ac *a, int b) {               /* BitIoStream.cpp:52-66 */
+    a->cur = (a->cur << 1) | b;
+    a->nbits++;
+    if (a->nbits == 8) {
+        if (a->len == a->cap) { a->cap = a->cap ? a->cap * 2 : 4096; a->buf = (uint8_t *)realloc(a->buf, a->cap); }
+        a->buf[a->len++] = (uint8_t)a->cur;
+        a->cur = 0; a->nbits = 0;
+    }
+}
+static int bit_read(orc_ac *a) {                         /* BitIoStream.cpp:19-34 + readCodeBit :131-136 */
+    if (a->eof) return 0;
+    if (a->nbits == 0) {
+        if (a->rpos >= a->len) { a->eof = 1; return 0; }
+        a->cur = a->buf[a->rpos++];
+        a->nbits = 8;
+    }
+    a->nbits--;
+    return (a->cur >> a->nbits) & 1;
+}
+static void ac_update(orc_ac *a, int enc, uint32_t symLow, uint32_t symHigh, uint32_t total) {  /* :34-69 */
+    if (a->low >= a->high || (a->low & AC_MASK) != a->low || (a->high & AC_MASK) != a->high) { a->error = 1; return; }
+    uint64_t range = a->high - a->low + 1;
+    if (range < AC_MINR || range > AC_MAXR) { a->error = 2; return; }
+    if (symLow == symHigh) { a->error = 3; return; }
+    if (total > AC_MINR) { a->error = 4; return; }
+    uint64_t newLow = a->low + symLow * range / total;
+    uint64_t newHigh = a->low + symHigh * range / total - 1;
+    a->low = newLow; a->high = newHigh;
+    while (((a->low ^ a->high) & AC_TOP) == 0) {
+        if (enc) {                                       /* ArithmeticEncoder::shift :157-164 */
+            int bit = (int)(a->low >> 31);
+            bit_write(a, bit);
+            for (; a->underflow > 0; a->underflow--) bit_write(a, bit ^ 1);
+        } else {                                         /* ArithmeticDecoder::shift :119-122 */
+            a->code = ((a->code << 1) & AC_MASK) | (uint64_t)bit_read(a);
+        }
+        a->low = (a->low << 1) & AC_MASK;
+        a->high = ((a->high << 1) & AC_MASK) | 1;
+    }
+    while ((a->low & ~a->high & AC_SECOND) != 0) {
+        if (enc) a->underflow++;                         /* :166-170 */
+        else a->code = (a->code & AC_TOP) | ((a->code << 1) & (AC_MASK >> 1)) | (uint64_t)bit_read(a);  /* :125-128 */
+        a->low = (a->low << 1) & (AC_MASK >> 1);
+        a->high = ((a->high << 1) & (AC_MASK >> 1)) | AC_TOP | 1;
+    }
+}
+
+ORC_API orc_ac *orc_ac_enc_open(void) {
+    orc_ac *a = (orc_ac *)calloc(1, sizeof(orc_ac));
+    a->low = 0; a->high = AC_MASK;
+    return a;
+}
+ORC_API orc_ac *orc_ac_dec_open(const uint8_t *bytes, size_t n) {
+    orc_ac *a = (orc_ac *)calloc(1, sizeof(orc_ac));
+    a->low = 0; a->high = AC_MASK;
+    a->buf = (uint8_t *)malloc(n ? n : 1); memcpy(a->buf, bytes, n); a->len = n; a->cap = n;
+    for (int i = 0; i < 32; i++) a->code = (a->code << 1) | (uint64_t)bit_read(a);   /* :72-79 */
+    return a;
+}
+ORC_API void orc_ac_close(orc_ac *a) { if (a) { free(a->buf); free(a); } }
+ORC_API int orc_ac_error(orc_ac *a) { return a->error; }
+
+/* Coder::my_encoder_slice[_mask]             extension/coder.cpp:30-48,70-89
+ * table int32 [num][ncode+1]; mask may be NULL (unmasked slice). */
+ORC_API void orc_ac_encode_slice(orc_ac *a, const int *table, int ncode, const int *label, const float *mask, int num) {
+    for (int i = 0; i < num; ++i) {
+        if (mask && mask[i] < 0.5f) continue;
+        const int *t = table + (long)i * (ncode + 1);
+        uint32_t sym = (uint32_t)label[i];
+        ac_update(a, 1, (uint32_t)t[sym], (uint32_t)t[sym + 1], (uint32_t)t[ncode]);
+    }
+}
+/* end_encoder: finish() writes a single 1 bit, stream pads zeros   coder.h:22-26, ArithmeticCoder.cpp:152-154 */
+ORC_API size_t orc_ac_enc_finish(orc_ac *a) {
+    bit_write(a, 1);
+    while (a->nbits != 0) bit_write(a, 0);
+    return a->len;
+}
+ORC_API const uint8_t *orc_ac_bytes(orc_ac *a) { return a->buf; }
+
+/* ArithmeticDecoder::read :82-116 + Coder::my_decoder_slice[_mask] coder.cpp:49-69,90-113.
+ * out float[num]; masked entries get file_value. */
+ORC_API void orc_ac_decode_slice(orc_ac *a, const int *table, int ncode, const float *mask, float file_value,
+                                 float *out, int num) {
+    for (int i = 0; i < num; ++i) {
+        if (mask && mask[i] < 0.5f) { out[i] = file_value; continue; }
+        const int *t = table + (long)i * (ncode + 1);
+        uint32_t total = (uint32_t)t[ncode];
+        uint64_t range = a->high - a->low + 1;
+        uint64_t offset = a->code - a->low;
+        uint64_t value = ((offset + 1) * total - 1) / range;
+        if (value * range / total > offset || value >= total) { a->error = 5; return; }
+        uint32_t start = 0, end = (uint32_t)ncode;
+        while (end - start > 1) {
+            uint32_t middle = (start + end) >> 1;
+            if ((uint32_t)t[middle] > value) end = middle; else start = middle;
+        }
+        uint32_t sym = start;
+        if (offset < (uint32_t)t[sym] * range / total || (uint32_t)t[sym + 1] * range / total <= offset) { a->error = 6; return; }
+        ac_update(a, 0, (uint32_t)t[sym], (uint32_t)t[sym + 1], total);
+        if (a->error) return;
+        if (a->code < a->low || a->code > a->high) { a->error = 7; return; }
+        out[i] = (float)sym;
+    }
+}
