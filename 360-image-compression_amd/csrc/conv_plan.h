@@ -1,0 +1,20 @@
+// conv_plan.h -- weight-independent schedule of one group-causal masked conv layer shape.
+#pragma once
+#include <vector>
+#include <cstdint>
+
+// One K-step record = 4 consecutive terms of one virtual lane's fmaf chain (K dim of
+// v_mfma_f32_16x16x4_f32) for a 16-row output tile.
+struct lic360_conv_plan {
+    int C, ngroup, nout, ksz, constrain, cin, cout, half;
+    int n_mtiles;
+    long total_rec;                       // K-step records over all output tiles (per stacked net)
+    std::vector<int> mt_rec_start;        // [n_mtiles+1]
+    std::vector<int> leaf_cnt;            // [n_mtiles][128] K-steps per leaf, VISITING order r (lane = bitrev7(r))
+    std::vector<int> term;                // [total_rec+PAD][4]  ti | kh<<16 | kw<<24
+    std::vector<int> wsrc;                // [total_rec][64]     flat index into weight[nout][C][k][k], -1 = zero
+    std::vector<int> mt_glo, mt_ghi;      // group range covered by each output tile
+    int *d_mt_rec_start = nullptr, *d_leaf_cnt = nullptr, *d_term = nullptr, *d_wsrc = nullptr;
+    int *d_mt_glo = nullptr, *d_mt_ghi = nullptr;
+};
+static const int LIC360_REC_PAD = 4;       // records readable past the end (software prefetch)

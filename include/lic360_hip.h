@@ -1,0 +1,138 @@
+/* lic360_hip.h -- C ABI of liblic360_hip.so, the MI355X (gfx950) implementation of the
+ * LIC360 spherical-tiling + latent entropy-coding hot path.
+ *
+ * This is the drop-in boundary: each entry point replaces one method of a
+ * class bound in the reference's pybind11 module `lic360` (extension/main.cpp:4-178).  The
+ * citation after each declaration names the reference interface it replaces.  Conventions:
+ *   - every pointer named *_dev / x / out ... is DEVICE memory (fp32, contiguous NCHW) unless
+ *     the name says host; `stream` is the caller's hipStream_t passed as void* (the reference
+ *     captured the ATen stream at construction, extension/base_opt.hpp:21-23);
+ *   - plain C types only -- no torch / ATen types cross this boundary;
+ *   - return value 0 = ok, non-zero = error; lic360_last_error() returns the message (the
+ *     reference printed CUDA errors and carried on, extension/caffe_cuda_macro.h:21-33);
+ *   - nothing here falls back to the CPU: if no HIP device is usable the call fails.
+ */
+#ifndef LIC360_HIP_H
+#define LIC360_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *lic360_last_error(void);
+int lic360_version(void);
+
+/* ---- A1-A3 sphere ops ------------------------------------------------------------------ */
+/* SpherePadOp.forward, not in place          extension/sphere_pad_cuda.cu:67-105 (kernel :29-46) */
+int lic360_sphere_pad(void *stream, const float *x, float *out, int nc, int h, int w, int pad);
+/* SpherePadOp.forward, inplace=true          extension/sphere_pad_cuda.cu:48-65; hp,wp = padded dims */
+int lic360_sphere_pad_inplace(void *stream, float *x, int nc, int hp, int wp, int pad);
+/* SphereTrimOp.forward                       extension/sphere_trim_cuda.cu:28-46 */
+int lic360_sphere_trim(void *stream, float *x, int nc, int h, int w, int pad);
+/* SphereCutEdgeOp.forward                    extension/sphere_cut_edge_cuda.cu:43-62 */
+int lic360_sphere_cut_edge(void *stream, const float *x, float *out, int nc, int h, int w, int pad);
+/* SphereLatScaleOp.forward / backward (same product)  extension/sphere_lat_scale_cuda.cu:40-58,69-87 */
+int lic360_sphere_lat_scale(void *stream, const float *x, const float *weight, float *out, int nc, int h, int w, int npart);
+
+/* ---- A4-A7, A18 pointwise ops ---------------------------------------------------------- */
+/* ImpMapOp.forward (mask may be NULL)        extension/imp_map_cuda.cu:112-136 */
+int lic360_imp_map(void *stream, const float *x, const float *imp, float *out, float *mask, int n, int c, int h, int w, int levels);
+/* ImpMapOp constraint tensor top[1]          extension/imp_map_cuda.cu:27-71 (host computes, device write) */
+int lic360_imp_map_constrain(void *stream, float *constrain, int n, int h, float rt, float scale_constrain);
+/* Imp2maskOp.forward                         extension/imp2mask_cuda.cu:41-57 */
+int lic360_imp2mask(void *stream, const float *x, float *out, int n, int c, int h, int w, int cpn);
+/* ScaleOp.forward                            extension/scale_cuda.cu:32-48 */
+int lic360_scale(void *stream, const float *x, float *out, long count, float bias, float scale);
+/* QuantOp.forward (train=false path); qidx may be NULL; wq_scratch/count are [c,levels] device buffers
+ *                                            extension/quant_cuda.cu:136-169 */
+int lic360_quant(void *stream, const float *x, const float *weight_b, float *wq_scratch, float *top, float *qidx, float *count,
+                 int n, int c, int h, int w, int levels);
+/* DquantOp.forward                           extension/dquant_cuda.cu:49-68 */
+int lic360_dquant(void *stream, const float *x, const float *mask, const float *weight_b, float *wc_scratch, float *out,
+                  int n, int c, int h, int w, int levels);
+/* DtowOp.forward (d2w: pixel shuffle, else unshuffle)   extension/dtow_cuda.cu:77-102 */
+int lic360_dtow(void *stream, const float *x, float *out, int n, int c, int h, int w, int stride, int d2w);
+
+/* ---- A17 layout ops ---------------------------------------------------------------------- */
+/* ContextReshapeOp.forward / backward(inverse=1)  extension/context_reshape_cuda.cu:42-60,74-92 */
+int lic360_context_reshape(void *stream, const float *x, float *out, int n, int c, int h, int w, int ngroup, int inverse);
+/* ContexShiftOp.forward (inv=0 zero-fills the skewed tensor first)  extension/contex_shift_cuda.cu:65-90 */
+int lic360_contex_shift(void *stream, const float *x, float *out, int n, int c, int hin, int w, int cpn, int inv);
+
+/* ---- A8 scan order ----------------------------------------------------------------------- */
+/* CodeContexOp.forward: HOST tables idx[2*h*w], plane_idx[h+w]   extension/code_contex_cuda.cu:11-38 */
+int lic360_code_contex(int h, int w, int *idx_host, int *plane_idx_host);
+/* window [start,len) of plane psum in the scan order (extension/cconv_dc_cuda.cu:374-376); len 0 past the end */
+int lic360_plane_window(int psum, int ngroup, int h, int w, const int *plane_idx_host, int *start, int *len);
+
+/* ---- A11-A13 plane gather / scatter / add -------------------------------------------------- */
+/* TileExtractOp.forward gather of plane psum -> out[n][len][cpn]   extension/tile_extract_cuda.cu:31-45,48-98 */
+int lic360_tile_extract(void *stream, const float *x, float *out, int n, int c, int h, int w, int ngroup,
+                        const int *idx_dev, int start, int len, int psum);
+/* TileExtractOp.forward_batch (3 stacked nets, slab stride cpn*h*w*(n/3))  extension/tile_extract_cuda.cu:101-151 */
+int lic360_tile_extract_batch(void *stream, const float *x, float *out, int n, int c, int h, int w, int ngroup,
+                              const int *idx_dev, int start, int len, int psum);
+/* TileInputOp.forward scatter of plane psum (already decremented) -> out[rep*n,g,h,w]  extension/tile_input_cuda.cu:27-76 */
+int lic360_tile_input(void *stream, const float *sym, float *out, int n, int g, int h, int w, float bias, float scale, int rep,
+                      const int *idx_dev, int start, int len, int psum);
+/* TileAddOp.forward y += x on plane psum      extension/tile_add_cuda.cu:22-60 */
+int lic360_tile_add(void *stream, float *y, const float *x, int n, int c, int h, int w, int ngroup,
+                    const int *idx_dev, int start, int len, int psum);
+
+/* ---- A14-A16 probability tables ------------------------------------------------------------ */
+/* EntropyGmmTableOp.forward / forward_batch: w,d are rewritten in place (softmax, sigma floor);
+ * out float[tn][nstep+1].  For forward_batch pass w=data, d=data+stride, m=data+2*stride.
+ *                                            extension/entropy_gmm_table_cuda.cu:109-135,161-191 */
+int lic360_gmm_table(void *stream, float *w, float *d, const float *m, float *out, int tn, int ng, int nstep,
+                     float bias, float total, float beta);
+/* EntropyTableOp.forward                     extension/entropy_table_cuda.cu:78-96 */
+int lic360_entropy_table(void *stream, const float *logits, float *out, int count, int nstep, float total);
+/* EntropyGmmOp.forward (loss + stored grads) / backward (scale stored grads by top_diff)
+ *                                            extension/entropy_gmm_cuda.cu:71-91,108-124 */
+int lic360_entropy_gmm(void *stream, const float *w, const float *d, const float *m, const float *label, float *loss,
+                       float *wd, float *dd, float *md, float *ld, int count, int ng);
+int lic360_entropy_gmm_backward(void *stream, float *wd, float *dd, float *md, float *ld, const float *top_diff, int count, int ng);
+
+/* ---- A9/A10 group-causal masked convolution ------------------------------------------------ */
+/* A plan holds the weight-independent schedule of one layer shape (term lists per 16-channel
+ * output tile in the reference's 128-lane tree order) in host and device memory. */
+typedef struct lic360_conv_plan lic360_conv_plan;
+/* shape of CconvEcOp/CconvDcOp ctor (channel, ngroup, nout, kernel_size, constrain)  extension/cconv_ec.hpp:7-16 */
+int lic360_conv_plan_create(int channel, int ngroup, int nout, int ksz, int constrain, lic360_conv_plan **plan);
+void lic360_conv_plan_destroy(lic360_conv_plan *plan);
+/* floats of packed weights per stacked net */
+long lic360_conv_plan_packed_floats(const lic360_conv_plan *plan);
+/* re-layout weight[nb][nout][channel][k][k] into MFMA A-fragments packed[nb][packed_floats] */
+int lic360_conv_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed);
+/* CconvEcOp.forward / forward_act / forward_batch / forward_act_batch (act NULL = no PReLU; nb = weight.size(0) or 1)
+ *                                            extension/cconv_ec_cuda.cu:99-121,170-192,242-265,317-339 */
+int lic360_cconv_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed, const float *bias,
+                    const float *act, float *out, int n, int h, int w, int nb);
+/* CconvDcOp.forward* for ONE plane psum: writes the plane's outputs into the persistent out[n,nout,h,w]
+ * (caller zero-fills at psum==0 like :385).  plane_idx_dev = device copy of CodeContex's prefix table.
+ *                                            extension/cconv_dc_cuda.cu:108-138,193-224,279-310,367-398 */
+int lic360_cconv_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed, const float *bias,
+                          const float *act, float *out, int n, int h, int w, int nb,
+                          const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum);
+
+/* ---- A19/A20 arithmetic coder (host side, as in the reference) ----------------------------- */
+/* Coder operates on HOST int32 tables exactly like the reference's Coder (extension/coder.h:10-63,
+ * extension/coder.cpp:30-113): the op API hands it CPU tensors. */
+typedef struct lic360_coder lic360_coder;
+lic360_coder *lic360_coder_enc_open(void);                                   /* Coder::start_encoder  coder.h:15-21 */
+int lic360_coder_encode_slice(lic360_coder *c, const int *table, int ncode, const int *label, const float *mask, int num);
+                                                                             /* encodes / encodes_mask coder.cpp:30-48,70-89 */
+long lic360_coder_enc_finish(lic360_coder *c);                               /* Coder::end_encoder    coder.h:22-26 */
+const uint8_t *lic360_coder_bytes(const lic360_coder *c);
+lic360_coder *lic360_coder_dec_open(const uint8_t *bytes, long n);           /* Coder::start_decoder  coder.h:30-35 */
+int lic360_coder_decode_slice(lic360_coder *c, const int *table, int ncode, const float *mask, float file_value, float *out, int num);
+                                                                             /* decodes / decodes_mask coder.cpp:49-69,90-113 */
+void lic360_coder_close(lic360_coder *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIC360_HIP_H */

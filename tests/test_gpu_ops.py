@@ -1,0 +1,302 @@
+"""GPU parity tests: every op of the drop-in `lic360` module (HIP, through the C ABI) against the
+CPU oracle on the same seeded inputs.  Integer / index / copy work and the masked convolution are
+required to be BIT-EXACT (np.array_equal); EntropyGmm (log-likelihood) is checked at 1e-5 as
+BASELINE.json's north_star states."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from util import conv_params, latent
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lic():
+    import lic360
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return lic360
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ masked convolution, encode order
+CONV_CASES = [
+    # ngroup, cin, cout, hidden, act, nb, N, H, W
+    (6, 1, 4, False, True, 3, 3, 8, 12),       # first layer of the latent net, small
+    (6, 4, 4, True, True, 3, 3, 8, 12),        # hidden layer
+    (6, 4, 3, True, False, 3, 3, 7, 19),       # last layer (cout=3), ragged H/W
+    (48, 1, 4, False, True, 3, 3, 4, 16),      # full channel count, first
+    (48, 4, 4, True, True, 3, 3, 8, 16),       # full channel count, hidden: 126 KB LDS tile
+    (48, 4, 3, True, False, 3, 6, 4, 16),      # last layer, two samples per net
+    (1, 1, 20, False, True, None, 1, 9, 11),   # importance-map net first layer (no batch)
+    (1, 8, 20, True, True, None, 2, 6, 10),    # 200 tap indices -> multi-index lanes
+    (1, 20, 5, True, False, None, 1, 5, 7),    # nout not a multiple of 16
+    (1, 144, 49, True, False, None, 1, 4, 6),  # importance-map net last layer, real channel counts
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "g%d_%dto%d_%s" % (c[0], c[1], c[2], "h" if c[3] else "f"))
+def test_cconv_ec_bit_exact(lic, case):
+    G, cin, cout, hidden, act, nb, N, H, W = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    C, nout = G * cin, G * cout
+    w, b, a = conv_params(rng, nb, nout, C, act=act)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    x[rng.random(x.shape) < 0.2] = 0.0
+    constrain = 6 if hidden else 5
+    ref = orc.cconv_ec(x, w, b, a, G, constrain)
+    op = lic.CconvEcOp(C, G, nout, 5, constrain, 0, False)
+    args = [dev(x), dev(w), dev(b)] + ([dev(a)] if act else [])
+    name = ("forward_act" if act else "forward") + ("_batch" if nb else "")
+    got = host(getattr(op, name)(*args)[0])
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
+
+
+def test_cconv_ec_matches_masked_conv2d(lic):
+    """Independent pin: equals F.conv2d with the mask_constrain rule (extension/mask_constrain_cuda.cu:17-41)."""
+    rng = np.random.default_rng(7)
+    G, cin, cout, H, W = 5, 4, 4, 6, 7
+    for hidden in (False, True):
+        C, nout = G * cin, G * cout
+        w, b, _ = conv_params(rng, None, nout, C, act=False)
+        x = rng.standard_normal((2, C, H, W)).astype(np.float32)
+        o, ti, kh, kw = np.meshgrid(np.arange(nout), np.arange(C), np.arange(5), np.arange(5), indexing="ij")
+        keep = (kh + kw + ti // cin < o // cout + 4) if not hidden else (kh + kw + ti // cin <= o // cout + 4)
+        ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w * keep).double(),
+                                         torch.from_numpy(b).double(), padding=2).numpy()
+        op = lic.CconvEcOp(C, G, nout, 5, 6 if hidden else 5, 0, False)
+        got = host(op.forward(dev(x), dev(w), dev(b))[0])
+        assert np.abs(got - ref).max() < 1e-4
+
+
+# ------------------------------------------------------------------ masked convolution, decode order
+@pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 6, 9), (6, 4, 4, True, True, 3, 3, 6, 9),
+                                  (6, 4, 3, True, False, 3, 3, 5, 8), (1, 1, 20, False, True, None, 1, 6, 7),
+                                  (1, 20, 7, True, False, None, 1, 5, 6)],
+                         ids=lambda c: "g%d_%dto%d" % (c[0], c[1], c[2]))
+def test_cconv_dc_planes_bit_exact(lic, case):
+    G, cin, cout, hidden, act, nb, N, H, W = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    C, nout = G * cin, G * cout
+    w, b, a = conv_params(rng, nb, nout, C, act=act)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    constrain = 6 if hidden else 5
+    idx, pidx = orc.code_contex(H, W)
+    ctx = lic.CodeContexOp(0, False)
+    p1, p2 = ctx.forward(dev(x))
+    assert np.array_equal(host(p1).reshape(-1), np.stack([idx[:H * W].reshape(H, W), idx[H * W:].reshape(H, W)], -1).reshape(-1)) \
+        or np.array_equal(host(p1).reshape(-1), idx)
+    assert np.array_equal(p2.numpy(), pidx)
+    op = lic.CconvDcOp(C, G, nout, 5, constrain, 0, False)
+    op.set_param(p1, p2)
+    op.restart()
+    ref = np.zeros((N, nout, H, W), np.float32)
+    args = [dev(x), dev(w), dev(b)] + ([dev(a)] if act else [])
+    name = ("forward_act" if act else "forward") + ("_batch" if nb else "")
+    for p in range(H + W + G - 2):
+        orc.cconv_dc_plane(x, w, b, a, ref, G, constrain, idx, pidx, p)
+        got = host(getattr(op, name)(*args)[0])
+        assert np.array_equal(got, ref), "plane %d" % p
+    # SURVEY.md §4 invariant: the final DC buffer equals the EC output (up to the sign of zero)
+    ec = orc.cconv_ec(x, w, b, a, G, constrain)
+    assert np.array_equal(ref, ec)
+
+
+# ------------------------------------------------------------------ plane gather / scatter / add
+def test_tile_ops(lic):
+    rng = np.random.default_rng(3)
+    G, cpn, H, W = 5, 3, 6, 8
+    y = rng.standard_normal((3, G * cpn, H, W)).astype(np.float32)
+    code = rng.integers(0, 8, (1, G, H, W)).astype(np.float32)
+    idx, pidx = orc.code_contex(H, W)
+    p1, p2 = lic.CodeContexOp(0, False).forward(dev(code))
+    ext_b, ext, ext_nl = lic.TileExtractOp(G, True, 0, False), lic.TileExtractOp(G, True, 0, False), lic.TileExtractOp(G, False, 0, False)
+    ipt, add = lic.TileInputOp(G, -3.5, 1.0, 3, 0, False), lic.TileAddOp(G, 0, False)
+    for o in (ext_b, ext, ext_nl, ipt, add):
+        o.set_param(p1, p2)
+        o.restart()
+    ya, yb = rng.standard_normal((3, G * 4, H, W)).astype(np.float32), rng.standard_normal((3, G * 4, H, W)).astype(np.float32)
+    ya_d, yb_d = dev(ya), dev(yb)
+    ob = np.zeros((3, cpn, H, W), np.float32)
+    ol = np.zeros((1, 1, H, W), np.float32)
+    onl = np.zeros((1, 1, H, W), np.float32)
+    oin = np.zeros((3, G, H, W), np.float32)
+    sym = np.zeros((1, 1, H, W), np.float32)
+    for p in range(H + W + G):            # two steps past the last plane on purpose
+        nb_ = orc.tile_extract_batch(y, ob.reshape(-1), G, idx, pidx, p)
+        z, le = ext_b.forward_batch(dev(y))
+        assert int(le[0]) == nb_
+        assert np.array_equal(host(z).reshape(-1), ob.reshape(-1))
+        nl = orc.tile_extract(code, ol.reshape(-1), G, True, idx, pidx, p)
+        z, le = ext.forward(dev(code))
+        assert int(le[0]) == nl and np.array_equal(host(z).reshape(-1)[:nl], ol.reshape(-1)[:nl])
+        orc.tile_extract(code, onl.reshape(-1), G, False, idx, pidx, p)
+        z, _ = ext_nl.forward(dev(code))
+        assert np.array_equal(host(z), onl)
+        sym.reshape(-1)[:] = rng.integers(0, 8, H * W)
+        orc.tile_input(sym.reshape(-1), oin.reshape(-1), 1, G, H, W, -3.5, 1.0, 3, idx, pidx, p)
+        assert np.array_equal(host(ipt.forward(dev(sym))[0]), oin)
+        if p < H + W + G - 2:
+            orc.tile_add(ya, yb, G, idx, pidx, p)
+            add.forward(ya_d, yb_d)
+            assert np.array_equal(host(ya_d), ya)
+
+
+# ------------------------------------------------------------------ CDF tables
+def test_gmm_table_batch_bit_exact(lic):
+    rng = np.random.default_rng(11)
+    H, W = 16, 32
+    tn = 300
+    data = np.zeros((3, 3, H, W), np.float32)
+    flat = data.reshape(-1)
+    stride = flat.size // 3
+    flat[:tn * 3] = rng.standard_normal(tn * 3) * 2                      # mixture logits
+    flat[stride:stride + tn * 3] = rng.uniform(-0.3, 2.5, tn * 3)        # sigma (some negative -> beta floor)
+    flat[2 * stride:2 * stride + tn * 3] = rng.uniform(-5, 5, tn * 3)    # mu (re-centred symbols live in [-3.5,3.5])
+    flat[stride:stride + 6] = [1e-6, -1.0, 0.0, 3e-4, 50.0, 1e-3]       # degenerate sigmas -> fix-up path
+    ref_in = data.copy()
+    ref = orc.gmm_table_batch(ref_in.reshape(-1), stride, tn)
+    op = lic.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, 0, False)
+    d = dev(data)
+    got = host(op.forward_batch(d, torch.tensor([tn], dtype=torch.int32))[0])
+    assert got.shape == (3 * H * W * 3 // 3 // 3 * 3 // 3, 9) or got.shape[1] == 9
+    assert np.array_equal(got[:tn], ref)
+    assert np.array_equal(host(d), ref_in)          # in-place softmax / sigma floor, like the reference
+    assert np.all(np.diff(got[:tn], axis=1) > 0) and np.all(got[:tn, 0] == 0) and np.all(got[:tn, 8] == 65536)
+    # non-batch entry point
+    w, dl, m = (np.ascontiguousarray(ref_in.reshape(3, -1)[i][:tn * 3].reshape(1, 1, tn, 3)) for i in range(3))
+    w0, d0, m0 = (data.reshape(3, -1)[i][:tn * 3].reshape(1, 1, tn, 3).copy() for i in range(3))
+    got2 = host(op.forward(dev(w0), dev(d0), dev(m0), torch.tensor([tn], dtype=torch.int32))[0])
+    assert np.array_equal(got2[:tn], ref)
+
+
+def test_gmm_table_close_to_float64(lic):
+    from scipy import special
+    rng = np.random.default_rng(12)
+    tn = 500
+    w = rng.standard_normal((tn, 3))
+    s = rng.uniform(0.05, 3, (tn, 3))
+    m = rng.uniform(-4, 4, (tn, 3))
+    sw = np.exp(w - w.max(1, keepdims=True))
+    sw /= sw.sum(1, keepdims=True)
+    edges = np.arange(1, 8) - 4.0
+    cdf = (sw[:, None, :] * (0.5 + 0.5 * special.erf((edges[None, :, None] - m[:, None, :]) / (s[:, None, :] + 1e-6) / np.sqrt(2)))).sum(-1)
+    exact = np.floor(65536 * cdf + 0.5)
+    op = lic.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, 0, False)
+    mk = lambda a: dev(a.astype(np.float32).reshape(1, 1, tn, 3))
+    got = host(op.forward(mk(w), mk(s), mk(m), torch.tensor([tn], dtype=torch.int32))[0])[:tn]
+    well = np.all(np.diff(exact, axis=1) > 2, axis=1) & (exact[:, 0] > 2) & (exact[:, -1] < 65533)   # rows the fix-up leaves alone
+    assert np.abs(got[well, 1:8] - exact[well]).max() <= 1
+
+
+def test_entropy_table_bit_exact(lic):
+    rng = np.random.default_rng(13)
+    n = 37
+    logits = (rng.standard_normal((1, 49, 8, 8)) * 3).astype(np.float32)
+    logits.reshape(-1)[:49] = -40.0
+    logits.reshape(-1)[5] = 10.0            # one-hot row -> many zero-width bins -> fix-up
+    ref = orc.entropy_table(logits.reshape(-1)[:n * 49].copy(), n, 49)
+    op = lic.EntropyTableOp(49, 65536, 0, False)
+    got = host(op.forward(dev(logits), torch.tensor([n], dtype=torch.int32))[0])
+    assert got.shape == (64, 50)
+    assert np.array_equal(got[:n], ref)
+    assert np.all(np.diff(ref, axis=1) > 0) and np.all(ref[:, -1] == 65536)
+
+
+def test_entropy_gmm_loss(lic):
+    from scipy import special
+    rng = np.random.default_rng(14)
+    M = 4000
+    w = rng.random((M, 3)).astype(np.float32)
+    w /= w.sum(1, keepdims=True)
+    d = rng.uniform(0.1, 3, (M, 3)).astype(np.float32)
+    m = rng.uniform(-3, 3, (M, 3)).astype(np.float32)
+    lab = rng.integers(-3, 4, (M, 1)).astype(np.float32)
+    op = lic.EntropyGmmOp(3, -1, 0, False)
+    loss = host(op.forward(dev(w), dev(d), dev(m), dev(lab))[0])
+    ref = orc.entropy_gmm(w, d, m, lab)
+    assert np.array_equal(loss, ref[0])                                   # same routines -> identical
+    phi = lambda z: 0.5 + 0.5 * special.erf(z / np.sqrt(2))
+    p = (w.astype(np.float64) * (phi((lab + 0.5 - m) / d) - phi((lab - 0.5 - m) / d))).sum(1)
+    assert np.abs(loss - (-np.log(p + 1e-7))).max() < 1e-5 * max(1.0, np.abs(np.log(p + 1e-7)).max())
+    grads = op.backward(dev(np.ones(M, np.float32)))
+    for g, r in zip(grads, ref[1:]):
+        assert np.allclose(host(g), r, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ sphere / pointwise / layout
+@pytest.mark.parametrize("shape,pad", [((1, 3, 16, 32), 2), ((2, 5, 9, 14), 2), ((1, 2, 6, 6), 1), ((1, 4, 8, 8), 3)])
+def test_sphere_ops(lic, shape, pad):
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(shape).astype(np.float32)
+    ref = orc.sphere_pad(x, pad)
+    assert np.array_equal(host(lic.SpherePadOp(pad, False, 0, False).forward(dev(x))[0]), ref)
+    # independent pin: roll/flip formulation of the ERP border
+    H, W = shape[2:]
+    mid = np.concatenate([x[..., -pad:], x, x[..., :pad]], -1)
+    top = mid[:, :, :pad][:, :, ::-1, ::-1]
+    bot = mid[:, :, -pad:][:, :, ::-1, ::-1]
+    assert np.array_equal(ref, np.concatenate([top, mid, bot], 2))
+    # in place: corrupt the apron, refresh it
+    y = ref.copy()
+    y[:, :, :pad] = 7; y[:, :, -pad:] = 7; y[..., :pad] = 7; y[..., -pad:] = 7
+    yd = dev(y)
+    out = lic.SpherePadOp(pad, True, 0, False).forward(yd)[0]
+    assert out.data_ptr() == yd.data_ptr() and np.array_equal(host(yd), ref)
+    assert np.array_equal(orc.sphere_pad_inplace(y.copy(), pad), ref)
+    td = dev(ref)
+    lic.SphereTrimOp(pad, 0, False).forward(td)
+    assert np.array_equal(host(td), orc.sphere_trim(ref.copy(), pad))
+    assert np.array_equal(host(lic.SphereCutEdgeOp(pad, 0, False).forward(dev(ref))[0]), x)
+    if shape[2] % 4 == 0:
+        wgt = rng.random((1, 1, shape[2] // 4)).astype(np.float32)
+        got = host(lic.SphereLatScaleOp(shape[2] // 4, 0, False).forward(dev(x), dev(wgt))[0])
+        assert np.array_equal(got, orc.sphere_lat_scale(x, wgt, shape[2] // 4))
+
+
+def test_dtow_impmap_quant(lic):
+    rng = np.random.default_rng(22)
+    N, C, H, W, levels = 2, 24, 6, 10, 6
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    up = host(lic.DtowOp(2, True, 0, False).forward(dev(x))[0])
+    assert np.array_equal(up, orc.dtow(x, 2, True))
+    assert np.array_equal(up, torch.nn.functional.pixel_shuffle(torch.from_numpy(x), 2).numpy())
+    assert np.array_equal(host(lic.DtowOp(2, False, 0, False).forward(dev(up))[0]), x)
+    imp = np.floor(rng.random((N, 1, H, W)) * levels).astype(np.float32) / levels
+    op = lic.ImpMapOp(levels, 0.1, 1.0, 0.5, 0.61, 0.61, 0, 3, 0, False)
+    out = op.forward(dev(x), dev(imp))
+    ro, rm = orc.imp_map(x, imp, levels)
+    assert np.array_equal(host(out[0]), ro) and np.array_equal(host(out[2]), rm)
+    assert np.allclose(host(out[1]), orc.imp_map_constrain(N, H, 0.5, 0.61), atol=1e-6)
+    lv = np.floor(rng.random((N, 1, H, W)) * (levels + 1)).astype(np.float32)
+    assert np.array_equal(host(lic.Imp2maskOp(levels, C, 0, False).forward(dev(lv))[0]), orc.imp2mask(lv, levels, C))
+    assert np.array_equal(host(lic.ScaleOp(-1.0, 2.0 / 47, 0, False).forward(dev(lv))[0]), orc.scale(lv, -1.0, np.float32(2.0 / 47)))
+    wb = np.concatenate([rng.uniform(-1, 0, (C, 1)), rng.uniform(-2, -0.5, (C, 7))], 1).astype(np.float32)
+    q = lic.QuantOp(C, 8, 0.9, 100, 2, 0.1, 0, False)
+    top, qidx = q.forward(dev(x), dev(wb), dev(np.zeros((C, 8), np.float32)), False)
+    rt, rq, rc = orc.quant(x, wb)
+    assert np.array_equal(host(top), rt) and np.array_equal(host(qidx), rq) and np.array_equal(host(q.count_data_), rc)
+    msk = (rng.random(x.shape) > 0.3).astype(np.float32)
+    assert np.array_equal(host(lic.DquantOp(C, 8, 0, False).forward(dev(rq), dev(msk), dev(wb))[0]), orc.dquant(rq, msk, wb))
+
+
+def test_context_layouts(lic):
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
+    cr = lic.ContextReshapeOp(4, 0, False)
+    got = host(cr.forward(dev(x))[0])
+    assert np.array_equal(got, orc.context_reshape(x, 4))
+    assert np.array_equal(got, x.reshape(2, 4, 3, 5, 7).transpose(0, 1, 3, 4, 2).reshape(-1, 3))
+    assert np.array_equal(host(cr.backward(dev(got))[0]), x)
+    sk = host(lic.ContexShiftOp(False, 3, 0, False).forward(dev(x))[0])
+    assert np.array_equal(sk, orc.contex_shift(x, 3, False))
+    assert np.array_equal(host(lic.ContexShiftOp(True, 3, 0, False).forward(dev(sk))[0]), x)
