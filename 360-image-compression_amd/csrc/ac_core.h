@@ -14,6 +14,12 @@
 #else
 #define AC_HD inline
 #endif
+// In device code one wave runs one coder with wave-uniform state; only lane 0 touches the byte buffer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AC_STORE_LANE ((threadIdx.x & 63) == 0)
+#else
+#define AC_STORE_LANE true
+#endif
 
 struct AcBitWriter {
     uint8_t *buf;      // destination
@@ -42,7 +48,7 @@ AC_HD void ac_bw_put(AcBitWriter &w, uint32_t v, int n) {
     while (w.nacc >= 8) {
         w.nacc -= 8;
         uint8_t b = (uint8_t)(w.acc >> w.nacc);
-        if (w.len < w.cap) w.buf[w.len] = b;
+        if (w.len < w.cap && AC_STORE_LANE) w.buf[w.len] = b;
         ++w.len;
     }
 }
@@ -127,10 +133,20 @@ AC_HD void ac_encode_finish(AcState &s, AcBitWriter &w) {
 
 AC_HD void ac_decode_start(AcState &s, AcBitReader &r) { s.code = ac_br_get(r, 32); }
 
+// floor(num / den) for num < 2^48, 2^30 < den <= 2^32, quotient < 2^17: one fp32 divide plus an exact
+// integer correction (the fp32 estimate is off by at most 1), instead of a 64-bit integer division.
+AC_HD uint32_t ac_div48(uint64_t num, uint64_t den) {
+    uint32_t q = (uint32_t)((float)num / (float)den);
+    int64_t r = (int64_t)num - (int64_t)((uint64_t)q * den);
+    while (r < 0) { --q; r += (int64_t)den; }
+    while (r >= (int64_t)den) { ++q; r -= (int64_t)den; }
+    return q;
+}
 // value in [0,total) that the current code points at
 AC_HD uint32_t ac_decode_target(const AcState &s, uint32_t total) {
     uint64_t range = (uint64_t)s.high - (uint64_t)s.low + 1;
     uint64_t offset = (uint64_t)s.code - (uint64_t)s.low;
+    if (total == 65536u) return ac_div48(((offset + 1) << 16) - 1, range);
     return (uint32_t)(((offset + 1) * total - 1) / range);
 }
 AC_HD void ac_decode_consume(AcState &s, AcBitReader &r, uint32_t symLow, uint32_t symHigh, uint32_t total) {

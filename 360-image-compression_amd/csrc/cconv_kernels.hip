@@ -87,15 +87,15 @@ LIC360_API int lic360_conv_pack(void *stream, const lic360_conv_plan *p, const f
 template <int NT>
 __global__ __launch_bounds__(EC_THREADS) void k_cconv_ec(
     const float *__restrict__ x, const float *__restrict__ packed, const float *__restrict__ bias, const float *__restrict__ act,
-    float *__restrict__ out, const int *__restrict__ mt_rec_start, const int *__restrict__ leaf_cnt, const int *__restrict__ term,
-    int C, int H, int W, int nout, int n_mtiles, int npb, long packed_per_net) {
+    const float *__restrict__ residual, float *__restrict__ out, const int *__restrict__ mt_rec_start, const int *__restrict__ leaf_cnt,
+    const int *__restrict__ term, int C, int H, int W, int nout, int n_mtiles, int npb, long packed_per_net, int x_mod) {
     extern __shared__ float xs[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * EC_TW, r0 = blockIdx.y * EC_TH, n = blockIdx.z;
     const int nbatch = n / npb;
     // ---- stage the zero-padded input tile: xs[ch][rr][cc] = x[n][ch][r0-2+rr][c0-2+cc]
     {
-        const float *xn = x + (long)n * C * H * W;
+        const float *xn = x + (long)(n % x_mod) * C * H * W;       // x_mod < N: the stacked nets share one input
         const int per = EC_ROWS * EC_COLS;
         for (int e = tid; e < C * per; e += EC_THREADS) {
             int ch = e / per, q = e % per, rr = q / EC_COLS, cc = q % EC_COLS;
@@ -165,7 +165,9 @@ __global__ __launch_bounds__(EC_THREADS) void k_cconv_ec(
                     if (gr < H) {
                         float sv = cur[j][reg] + bsv;
                         if (act) sv = sv > 0 ? sv : sv * av;        // cconv_ec_cuda.cu:311-312
-                        out[(((long)n * nout + o) * H + gr) * W + gc] = sv;
+                        const long oi = (((long)n * nout + o) * H + gr) * W + gc;
+                        if (residual) sv = sv + residual[oi];       // fused `conv2(conv1(x)) + x` (lic360_demo.py:41)
+                        out[oi] = sv;
                     }
                 }
             }
@@ -175,7 +177,12 @@ __global__ __launch_bounds__(EC_THREADS) void k_cconv_ec(
 
 LIC360_API int lic360_cconv_ec(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
                                const float *act, float *out, int n, int h, int w, int nb) {
-    ARG_CHECK(p && x && packed && bias && out && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0);
+    return lic360_cconv_ec_ex(stream, p, x, packed, bias, act, nullptr, out, n, h, w, nb, n);
+}
+
+LIC360_API int lic360_cconv_ec_ex(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
+                                  const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod) {
+    ARG_CHECK(p && x && packed && bias && out && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
     ARG_CHECK(p->ksz == 5);
     size_t lds = (size_t)p->C * EC_PL * sizeof(float);
     ARG_CHECK(lds <= 160 * 1024);
@@ -185,9 +192,9 @@ LIC360_API int lic360_cconv_ec(void *stream, const lic360_conv_plan *p, const fl
         attr_set = true;
     }
     dim3 grid((w + EC_TW - 1) / EC_TW, (h + EC_TH - 1) / EC_TH, n);
-    hipLaunchKernelGGL(k_cconv_ec<EC_TH>, grid, dim3(EC_THREADS), lds, (hipStream_t)stream, x, packed, bias, act, out,
+    hipLaunchKernelGGL(k_cconv_ec<EC_TH>, grid, dim3(EC_THREADS), lds, (hipStream_t)stream, x, packed, bias, act, residual, out,
                        p->d_mt_rec_start, p->d_leaf_cnt, p->d_term, p->C, h, w, p->nout, p->n_mtiles, n / nb,
-                       lic360_conv_plan_packed_floats(p));
+                       lic360_conv_plan_packed_floats(p), x_mod);
     LAUNCH_CHECK();
     return 0;
 }
@@ -200,7 +207,8 @@ __global__ __launch_bounds__(64) void k_cconv_dc(
     const float *__restrict__ x, const float *__restrict__ packed, const float *__restrict__ bias, const float *__restrict__ act,
     float *__restrict__ out, const int *__restrict__ mt_rec_start, const int *__restrict__ leaf_cnt, const int *__restrict__ term,
     const int *__restrict__ mt_glo, const int *__restrict__ mt_ghi, const int *__restrict__ idx, const int *__restrict__ plane_idx,
-    int C, int H, int W, int nout, int cout, int half, int npb, long packed_per_net, int psum) {
+    int C, int H, int W, int nout, int cout, int half, int npb, long packed_per_net, int psum,
+    const float *__restrict__ residual, int x_mod, long x_cs, long x_hs, long x_ws, long o_cs, long o_hs, long o_ws) {
     const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
     const int mi = blockIdx.y, n = blockIdx.z, nbatch = n / npb;
     // diagonal range of this tile on this plane
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64) void k_cconv_dc(
     const int q = qbeg + blockIdx.x * 16 + col;
     const bool live = q < qend;
     const int th = live ? idx[q] : 0, tw = live ? idx[q + H * W] : 0;
-    const float *xn = x + (long)n * C * H * W;
+    const float *xn = x + (long)(n % x_mod) * C * x_cs;
     const float *wp = packed + (long)nbatch * packed_per_net;
     long rec = mt_rec_start[mi];
     const int *cnt = leaf_cnt + mi * 128;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(64) void k_cconv_dc(
     {                                                                               \
         int ph = th + ((T >> 16) & 0xff) - half, pw = tw + ((T >> 24) & 0xff) - half; \
         dst = 0.0f;                                                                 \
-        if (live && ph >= 0 && ph < H && pw >= 0 && pw < W) dst = xn[((long)(T & 0xffff) * H + ph) * W + pw]; \
+        if (live && ph >= 0 && ph < H && pw >= 0 && pw < W) dst = xn[(long)(T & 0xffff) * x_cs + ph * x_hs + pw * x_ws]; \
     }
     float a_cur = wp[rec * 64 + lane], b_cur;
     int t_cur = term[rec * 4 + kq];
@@ -249,7 +257,9 @@ __global__ __launch_bounds__(64) void k_cconv_dc(
             int bid = nbatch * nout + o;
             float sv = cur[0][reg] + bias[bid];
             if (act) { if (sv < 0) sv = sv * act[bid]; }            // cconv_dc_cuda.cu:360-362
-            out[(((long)n * nout + o) * H + th) * W + tw] = sv;
+            const long oi = ((long)n * nout + o) * o_cs + th * o_hs + tw * o_ws;
+            if (residual) sv = sv + residual[oi];                   // fused TileAdd (tile_add_cuda.cu:35)
+            out[oi] = sv;
         }
     }
 }
@@ -257,7 +267,18 @@ __global__ __launch_bounds__(64) void k_cconv_dc(
 LIC360_API int lic360_cconv_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
                                      const float *act, float *out, int n, int h, int w, int nb,
                                      const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum) {
+    return lic360_cconv_dc_plane_ex(stream, p, x, packed, bias, act, nullptr, out, n, h, w, nb, idx_dev, plane_idx_dev, plane_idx_host,
+                                    psum, n, 0);
+}
+
+LIC360_API int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
+                                        const float *act, const float *residual, float *out, int n, int h, int w, int nb,
+                                        const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum,
+                                        int x_mod, int skewed) {
     ARG_CHECK(p && x && packed && bias && out && idx_dev && plane_idx_dev && plane_idx_host && n > 0 && nb > 0 && n % nb == 0);
+    ARG_CHECK(x_mod > 0 && x_mod <= n);
+    // activation layout: NCHW, or diagonal-major [n][c][s=th+tw][th] (positions of one anti-diagonal contiguous)
+    long cs = skewed ? (long)(h + w - 1) * h : (long)h * w, hs = skewed ? h + 1 : w, ws = skewed ? h : 1;
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
     // widest tile range on this plane -> grid.x (blocks past a tile's range exit immediately)
     int maxpos = 0;
@@ -273,7 +294,7 @@ LIC360_API int lic360_cconv_dc_plane(void *stream, const lic360_conv_plan *p, co
     dim3 grid((maxpos + 15) / 16, p->n_mtiles, n);
     hipLaunchKernelGGL(k_cconv_dc, grid, dim3(64), 0, (hipStream_t)stream, x, packed, bias, act, out, p->d_mt_rec_start, p->d_leaf_cnt,
                        p->d_term, p->d_mt_glo, p->d_mt_ghi, idx_dev, plane_idx_dev, p->C, h, w, p->nout, p->cout, p->half, n / nb,
-                       lic360_conv_plan_packed_floats(p), psum);
+                       lic360_conv_plan_packed_floats(p), psum, residual, x_mod, cs, hs, ws, cs, hs, ws);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,351 @@
+// codec_fused.hip -- device-resident latent codec (rows D1/D2 of SURVEY.md §8a as ONE pipeline per
+// batch of images): the whole of EntEncoderFast.forward / EntDecoder.forward
+// (test/lic360_demo.py:119-141, 215-238) without the reference's per-plane GPU<->CPU round trips.
+//
+// encode:  prep (code-3.5)*mask  ->  12 masked-conv layers (MFMA, residual adds fused)  ->
+//          per-symbol GMM CDF build in coding order, keeping only (cdf[sym], cdf[sym+1])  ->
+//          one arithmetic-coder wave per image writing the bitstream into HBM.
+// decode:  per anti-diagonal plane p: 12 plane-restricted conv layers on a diagonal-major
+//          activation layout  ->  one wave per image: 64 CDF tables in parallel, then the serial
+//          range decoder on wave-uniform state, symbols scattered straight into the next plane's input.
+// Bitstreams are byte-identical to the per-plane drivers and to the CPU oracle.
+#include "common.h"
+#include "conv_plan.h"
+#include "ac_core.h"
+#include "lic360_exact_math.h"
+#include <vector>
+#include <cstring>
+#include <algorithm>
+
+struct AcDevState {            // per-image decoder state carried across planes
+    uint32_t low, high, code;
+    int nacc, error, pad;
+    long pos;
+    unsigned long long acc;
+};
+
+struct lic360_codec {
+    int G, H, W, maxB, S, P, HW;
+    lic360_conv_plan *plan[3];                 // first, hidden, last
+    float *packed[12], *bias[12], *act[12];
+    std::vector<int> h_idx, h_pidx, h_plane_start;
+    int *d_idx, *d_pidx, *d_plane_start;
+    float *e_x0, *e_buf[3];
+    uint2 *e_rec;
+    float *d_x0, *d_act[11], *d_y;
+    AcDevState *d_state;
+    bool layer_set[12];
+};
+
+static int plan_of(int layer) { return layer == 0 ? 0 : (layer == 11 ? 2 : 1); }
+
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------------------------ encode
+__global__ void k_enc_prep(const float *__restrict__ code, const float *__restrict__ mask, float *__restrict__ x0, long total) {
+    GRID_STRIDE(i, total) x0[i] = (code[i] - 3.5f) * mask[i];        // lic360_demo.py:130
+}
+
+// 9-entry GMM CDF of one symbol from the three nets' outputs (weights, sigma, mu; 3 components each)
+__device__ __forceinline__ void gmm_cdf9(const float *lw_in, const float *ld_in, const float *lm, int *T) {
+    float lw[3] = {lw_in[0], lw_in[1], lw_in[2]}, ld[3];
+    lic360_softmax_inplace(lw, 3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ld[i] = lic360_sigma_floor(ld_in[i], 1e-6f);
+    float t[9];
+    t[0] = 0.0f;
+    t[8] = 65536.0f;
+#pragma unroll
+    for (int pt = 1; pt < 8; ++pt) t[pt] = (float)lic360_gmm_cdf_entry(pt, 3.5f, 65536.0f, lw, ld, lm, 3);
+    lic360_cdf_fixup(t, 8, 0);
+#pragma unroll
+    for (int pt = 0; pt < 9; ++pt) T[pt] = (int)t[pt];
+}
+
+// one thread per latent element (NCHW-linear, coalesced reads); the (cdf[sym], cdf[sym+1]) pair is
+// written at the symbol's position in coding order: plane p = g+th+tw, diagonals ascending inside a
+// plane, rows ascending inside a diagonal (extension/code_contex_cuda.cu:19-31, tile_extract_cuda.cu:36-41).
+__global__ void k_enc_tables(const float *__restrict__ y, const float *__restrict__ code, const float *__restrict__ mask,
+                             const int *__restrict__ pidx, const int *__restrict__ plane_start, uint2 *__restrict__ rec,
+                             int B, int G, int H, int W) {
+    const long HW = (long)H * W, per = (long)G * HW, total = per * B;
+    GRID_STRIDE(i, total) {
+        int tw = (int)(i % W), th = (int)((i / W) % H), g = (int)((i / HW) % G), b = (int)(i / per);
+        int s = th + tw, p = s + g;
+        int la = p >= G ? p - G + 1 : 0;
+        long k = plane_start[p] + (pidx[s] - pidx[la]) + (th - (s >= W ? s - W + 1 : 0));
+        uint2 r = make_uint2(0u, 0u);
+        if (!(mask[i] < 0.5f)) {                                     // coder.cpp:79
+            float v[9];
+#pragma unroll
+            for (int net = 0; net < 3; ++net)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[net * 3 + c] = y[(((long)(net * B + b) * (3 * G) + g * 3 + c) * H + th) * W + tw];
+            int T[9];
+            gmm_cdf9(v, v + 3, v + 6, T);
+            int sym = (int)code[i];
+            sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
+            r = make_uint2((unsigned)T[sym], (unsigned)T[sym + 1]);
+        }
+        rec[(long)b * per + k] = r;
+    }
+}
+
+// one wave per image; coder state is wave-uniform, lane 0 stores the bytes
+__global__ __launch_bounds__(64) void k_ac_encode(const uint2 *__restrict__ rec, long n, uint8_t *__restrict__ bytes, long cap,
+                                                  int *__restrict__ nbytes, int *__restrict__ err) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint2 *r = rec + (long)b * n;
+    AcState st;
+    ac_init(st);
+    AcBitWriter bw;
+    ac_bw_init(bw, bytes + (long)b * cap, cap);
+    for (long base = 0; base < n; base += 64) {
+        uint2 v = make_uint2(0u, 0u);
+        if (base + lane < n) v = r[base + lane];
+        int cnt = (n - base) < 64 ? (int)(n - base) : 64;
+        for (int j = 0; j < cnt; ++j) {
+            uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.x, j);
+            uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)v.y, j);
+            if (hi != 0u) ac_encode_symbol(st, bw, lo, hi, 65536u);
+        }
+    }
+    ac_encode_finish(st, bw);
+    if (lane == 0) {
+        nbytes[b] = (int)bw.len;
+        err[b] = st.error | (bw.len > cap ? 16 : 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+__global__ void k_dec_init(const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes, AcDevState *__restrict__ state, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    AcBitReader rd;
+    ac_br_init(rd, bytes + (long)b * cap, nbytes[b]);
+    AcState st;
+    ac_init(st);
+    ac_decode_start(st, rd);
+    AcDevState d;
+    d.low = st.low; d.high = st.high; d.code = st.code; d.error = 0; d.pad = 0;
+    d.pos = rd.pos; d.acc = rd.acc; d.nacc = rd.nacc;
+    state[b] = d;
+}
+
+// One wave per image and plane: tables for 64 plane positions in parallel, serial range decode on the
+// wave-uniform state, then scatter of (sym-3.5 | 0) into the diagonal-major input of the next plane and
+// of the decoded symbol into the NCHW output (= TileInput + `b[0:1] + 3.5*mask`, lic360_demo.py:222,236-237).
+__global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, const float *__restrict__ mask, const int *__restrict__ idx,
+                                                  int start, int len, int p, AcDevState *__restrict__ state,
+                                                  const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes,
+                                                  float *__restrict__ x0, float *__restrict__ code_out, int B, int G, int H, int W) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int HW = H * W, S = H + W - 1;
+    AcDevState ds = state[b];
+    AcState st;
+    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = ds.error;
+    AcBitReader rd;
+    rd.buf = bytes + (long)b * cap; rd.len = nbytes[b]; rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc;
+    for (int base = 0; base < len; base += 64) {
+        const int cnt = (len - base) < 64 ? (len - base) : 64;
+        const bool live = lane < cnt;
+        const int q = start + base + (live ? lane : 0);
+        const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
+        const long nchw = (((long)b * G + g) * H + th) * W + tw;
+        const bool coded = live && !(mask[nchw] < 0.5f);
+        int T[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) T[k] = 0;
+        if (coded) {
+            float v[9];
+#pragma unroll
+            for (int net = 0; net < 3; ++net)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[net * 3 + c] = y[(((long)(net * B + b) * (3 * G) + g * 3 + c) * S + (th + tw)) * H + th];
+            gmm_cdf9(v, v + 3, v + 6, T);
+        }
+        const unsigned long long cmask = __ballot(coded);
+        int symv = 0;
+        for (int j = 0; j < cnt; ++j) {
+            if (!((cmask >> j) & 1ull)) continue;
+            int t[9];
+            t[0] = 0; t[8] = 65536;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t[k] = __builtin_amdgcn_readlane(T[k], j);
+            uint32_t target = ac_decode_target(st, 65536u);
+            int sym = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) sym += (target >= (uint32_t)t[k]) ? 1 : 0;
+            uint32_t lo = 0, hi = 65536;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (sym == k) { lo = (uint32_t)t[k]; hi = (uint32_t)t[k + 1]; }
+            ac_decode_consume(st, rd, lo, hi, 65536u);
+            symv = (lane == j) ? sym : symv;
+        }
+        if (live) {
+            x0[(((long)b * G + g) * S + (th + tw)) * H + th] = coded ? (float)symv - 3.5f : 0.0f;
+            code_out[nchw] = coded ? (float)symv : 0.0f;
+        }
+    }
+    if (lane == 0) {
+        ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error = st.error;
+        ds.pos = rd.pos; ds.acc = rd.acc; ds.nacc = rd.nacc;
+        state[b] = ds;
+    }
+}
+
+__global__ void k_collect_err(const AcDevState *__restrict__ state, int *__restrict__ err, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) err[b] = state[b].error;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <class T>
+static int dmalloc(T **p, size_t n) {
+    HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+
+LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic360_codec **out) {
+    ARG_CHECK(out && ngroup > 0 && ngroup < 128 && h > 0 && w > 0 && h < 4096 && w < 4096 && max_batch > 0);
+    lic360_codec *c = new lic360_codec();
+    memset(c->layer_set, 0, sizeof(c->layer_set));
+    c->G = ngroup; c->H = h; c->W = w; c->maxB = max_batch; c->S = h + w - 1; c->P = h + w + ngroup - 2; c->HW = h * w;
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = nullptr;
+    int rc = 0;
+    rc |= lic360_conv_plan_create(ngroup * 1, ngroup, ngroup * 4, 5, 5, &c->plan[0]);
+    rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 4, 5, 6, &c->plan[1]);
+    rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 3, 5, 6, &c->plan[2]);
+    if (rc) return 1;
+    c->h_idx.resize(2 * (size_t)c->HW);
+    c->h_pidx.resize(h + w);
+    lic360_code_contex(h, w, c->h_idx.data(), c->h_pidx.data());
+    c->h_plane_start.resize(c->P + 1);
+    int acc = 0;
+    for (int p = 0; p < c->P; ++p) {
+        int st, ln;
+        lic360_plane_window(p, ngroup, h, w, c->h_pidx.data(), &st, &ln);
+        c->h_plane_start[p] = acc;
+        acc += ln;
+    }
+    c->h_plane_start[c->P] = acc;
+    if (acc != ngroup * c->HW) { lic360_set_error("internal: plane schedule does not cover the latent"); return 1; }
+    rc |= dmalloc(&c->d_idx, c->h_idx.size());
+    rc |= dmalloc(&c->d_pidx, c->h_pidx.size());
+    rc |= dmalloc(&c->d_plane_start, c->h_plane_start.size());
+    if (rc) return 1;
+    HIP_TRY(hipMemcpy(c->d_idx, c->h_idx.data(), c->h_idx.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_pidx, c->h_pidx.data(), c->h_pidx.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_plane_start, c->h_plane_start.data(), c->h_plane_start.size() * 4, hipMemcpyHostToDevice));
+    const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->S * h;
+    rc |= dmalloc(&c->e_x0, B * G * HW);
+    for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], 3 * B * 4 * G * HW);
+    rc |= dmalloc(&c->e_rec, B * G * HW);
+    rc |= dmalloc(&c->d_x0, B * G * SK);
+    for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], 3 * B * 4 * G * SK);
+    rc |= dmalloc(&c->d_y, 3 * B * 3 * G * SK);
+    rc |= dmalloc(&c->d_state, B);
+    if (rc) return 1;
+    // decode activations are only ever read where already written or with a zero weight; they must be finite
+    HIP_TRY(hipMemset(c->d_x0, 0, B * G * SK * 4));
+    for (int i = 0; i < 11; ++i) HIP_TRY(hipMemset(c->d_act[i], 0, 3 * B * 4 * G * SK * 4));
+    HIP_TRY(hipMemset(c->d_y, 0, 3 * B * 3 * G * SK * 4));
+    *out = c;
+    return 0;
+}
+
+LIC360_API void lic360_codec_destroy(lic360_codec *c) {
+    if (!c) return;
+    for (int i = 0; i < 3; ++i) lic360_conv_plan_destroy(c->plan[i]);
+    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); }
+    (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->d_plane_start);
+    (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
+    (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
+    (void)hipFree(c->d_y); (void)hipFree(c->d_state);
+    delete c;
+}
+
+LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, const float *weight, const float *bias, const float *act) {
+    ARG_CHECK(c && layer >= 0 && layer < 12 && weight && bias);
+    ARG_CHECK((act != nullptr) == (layer != 11));
+    lic360_conv_plan *p = c->plan[plan_of(layer)];
+    long nper = lic360_conv_plan_packed_floats(p);
+    if (!c->packed[layer]) {
+        if (dmalloc(&c->packed[layer], 3 * (size_t)nper)) return 1;
+        if (dmalloc(&c->bias[layer], 3 * (size_t)p->nout)) return 1;
+        if (act && dmalloc(&c->act[layer], 3 * (size_t)p->nout)) return 1;
+    }
+    if (lic360_conv_pack(stream, p, weight, 3, c->packed[layer])) return 1;
+    HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->layer_set[layer] = true;
+    return 0;
+}
+
+static int check_ready(const lic360_codec *c, int B) {
+    ARG_CHECK(c && B > 0 && B <= c->maxB);
+    for (int i = 0; i < 12; ++i)
+        if (!c->layer_set[i]) { lic360_set_error("codec layer %d has no weights (call lic360_codec_set_layer)", i); return 2; }
+    return 0;
+}
+
+LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *code, const float *mask, int B,
+                                   uint8_t *bytes, long cap, int *nbytes, int *err) {
+    if (check_ready(c, B)) return 2;
+    ARG_CHECK(code && mask && bytes && nbytes && err && cap > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int G = c->G, H = c->H, W = c->W;
+    const long total = (long)B * G * c->HW;
+    hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total);
+    LAUNCH_CHECK();
+    float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
+    if (lic360_cconv_ec_ex(stream, c->plan[0], c->e_x0, c->packed[0], c->bias[0], c->act[0], nullptr, cur, 3 * B, H, W, 3, B)) return 1;
+    for (int blk = 0; blk < 5; ++blk) {
+        int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
+        if (lic360_cconv_ec_ex(stream, c->plan[1], cur, c->packed[a], c->bias[a], c->act[a], nullptr, t1, 3 * B, H, W, 3, 3 * B)) return 1;
+        if (lic360_cconv_ec_ex(stream, c->plan[1], t1, c->packed[b2], c->bias[b2], c->act[b2], cur, nxt, 3 * B, H, W, 3, 3 * B)) return 1;
+        float *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (lic360_cconv_ec_ex(stream, c->plan[2], cur, c->packed[11], c->bias[11], nullptr, nullptr, t1, 3 * B, H, W, 3, 3 * B)) return 1;
+    hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx, c->d_plane_start,
+                       c->e_rec, B, G, H, W);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
+                                   const float *mask, int B, float *code_out, int *err) {
+    if (check_ready(c, B)) return 2;
+    ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int G = c->G, H = c->H, W = c->W;
+    hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
+    LAUNCH_CHECK();
+    const int *pih = c->h_pidx.data();
+    for (int p = 0; p < c->P; ++p) {
+        // plane p of all 12 layers (x0 already holds planes < p)
+        if (lic360_cconv_dc_plane_ex(stream, c->plan[0], c->d_x0, c->packed[0], c->bias[0], c->act[0], nullptr, c->d_act[0], 3 * B, H, W, 3,
+                                     c->d_idx, c->d_pidx, pih, p, B, 1)) return 1;
+        for (int blk = 0; blk < 5; ++blk) {
+            int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
+            if (lic360_cconv_dc_plane_ex(stream, c->plan[1], c->d_act[a - 1], c->packed[a], c->bias[a], c->act[a], nullptr, c->d_act[a],
+                                         3 * B, H, W, 3, c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+            if (lic360_cconv_dc_plane_ex(stream, c->plan[1], c->d_act[a], c->packed[b2], c->bias[b2], c->act[b2], c->d_act[a - 1], c->d_act[b2],
+                                         3 * B, H, W, 3, c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+        }
+        if (lic360_cconv_dc_plane_ex(stream, c->plan[2], c->d_act[10], c->packed[11], c->bias[11], nullptr, nullptr, c->d_y, 3 * B, H, W, 3,
+                                     c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+        int start, len;
+        lic360_plane_window(p, G, H, W, pih, &start, &len);
+        hipLaunchKernelGGL(k_dec_plane, dim3(B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
+                           c->d_x0, code_out, B, G, H, W);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -118,6 +118,16 @@ int lic360_cconv_dc_plane(void *stream, const lic360_conv_plan *plan, const floa
                           const float *act, float *out, int n, int h, int w, int nb,
                           const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum);
 
+/* Extended forms used by the fused codec: `residual` (same layout as out, may be NULL) is added after the
+ * activation (EntropyResidualBlock*: `conv2(conv1(x)) + x`, test/lic360_demo.py:29-41, extension/tile_add_cuda.cu:35);
+ * x_mod < n lets the stacked nets share one input (the reference concatenates three copies, lic360_demo.py:131);
+ * skewed != 0 selects the diagonal-major activation layout [n][c][th+tw][th] for x, residual and out. */
+int lic360_cconv_ec_ex(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed, const float *bias,
+                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
+int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed, const float *bias,
+                             const float *act, const float *residual, float *out, int n, int h, int w, int nb,
+                             const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod, int skewed);
+
 /* ---- A19/A20 arithmetic coder (host side, as in the reference) ----------------------------- */
 /* Coder operates on HOST int32 tables exactly like the reference's Coder (extension/coder.h:10-63,
  * extension/coder.cpp:30-113): the op API hands it CPU tensors. */
@@ -131,6 +141,24 @@ lic360_coder *lic360_coder_dec_open(const uint8_t *bytes, long n);           /* 
 int lic360_coder_decode_slice(lic360_coder *c, const int *table, int ncode, const float *mask, float file_value, float *out, int num);
                                                                              /* decodes / decodes_mask coder.cpp:49-69,90-113 */
 void lic360_coder_close(lic360_coder *c);
+
+/* ---- D1/D2 device-resident latent codec ------------------------------------------------------- */
+/* One object per (ngroup, h, w) entropy-domain shape and GPU; replaces EntEncoderFast / EntDecoder
+ * (test/lic360_demo.py:95-141,191-238) for batches of up to max_batch images.  All pointers are device
+ * memory; bitstreams live in HBM as bytes[b*cap .. b*cap+nbytes[b]) and are byte-identical to what
+ * Coder::end_encoder would have written to `<code>` (extension/coder.h:22-26). */
+typedef struct lic360_codec lic360_codec;
+int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic360_codec **codec);
+void lic360_codec_destroy(lic360_codec *codec);
+/* layer 0..11 of the 3 stacked nets [weight, sigma, mu]: weight [3,nout,cin_total,5,5], bias/act [3,nout]
+ * (act NULL for layer 11) -- the tensors cast_entropy_parameter fills (test/lic360_demo.py:296-311) */
+int lic360_codec_set_layer(void *stream, lic360_codec *codec, int layer, const float *weight, const float *bias, const float *act);
+/* code/mask [b,ngroup,h,w] fp32 (symbols 0..7, mask 0/1) -> bitstreams; err[b] != 0 flags a coder fault or cap overflow */
+int lic360_codec_encode(void *stream, lic360_codec *codec, const float *code, const float *mask, int b,
+                        uint8_t *bytes, long cap, int *nbytes, int *err);
+/* bitstreams + mask -> code_out [b,ngroup,h,w] (decoded symbol where mask, 0 elsewhere: `b[0:1] + 3.5*mask`, lic360_demo.py:236-237) */
+int lic360_codec_decode(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
+                        const float *mask, int b, float *code_out, int *err);
 
 #ifdef __cplusplus
 }
