@@ -1,0 +1,113 @@
+"""FusedCodec -- host wrapper of the device-resident latent codec (C ABI lic360_codec_*, csrc/codec_fused.hip).
+
+Replaces the EntEncoderFast / EntDecoder pair (test/lic360_demo.py:95-141,191-238) for batches of images:
+inputs, activations, CDF tables, coder state and bitstreams all stay in HBM; the host only queues
+kernels.  Bitstreams are byte-identical to the per-plane drivers in lic360_codec.py and to the oracle.
+torch is used for device buffers and streams only.
+"""
+import ctypes as C
+
+import torch
+
+import lic360
+from lic360 import _lib, _chk, _p, _stream, Lic360Error
+
+_lib.lic360_codec_destroy.argtypes = [C.c_void_p]
+
+
+class FusedCodec(object):
+    def __init__(self, ngroup, h, w, max_batch, device=0, cap_bytes=None):
+        self.G, self.H, self.W, self.maxB, self.device = int(ngroup), int(h), int(w), int(max_batch), int(device)
+        # worst case of this coder is < 2.1 bytes/symbol (16-bit CDF, frequency >= 1); 1 byte/symbol is ample for
+        # any real table and overflow is reported through err[] rather than written out of bounds
+        self.cap = int(cap_bytes) if cap_bytes else max(4096, self.G * self.H * self.W)
+        self._h = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            _chk(_lib.lic360_codec_create(self.G, self.H, self.W, self.maxB, C.byref(self._h)))
+        dev = "cuda:%d" % self.device
+        self.bytes = torch.zeros((self.maxB, self.cap), dtype=torch.uint8, device=dev)
+        self.nbytes = torch.zeros((self.maxB,), dtype=torch.int32, device=dev)
+        self.err = torch.zeros((self.maxB,), dtype=torch.int32, device=dev)
+        self.code_out = torch.zeros((self.maxB, self.G, self.H, self.W), dtype=torch.float32, device=dev)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lic360_codec_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------------
+    def set_layer(self, layer, weight, bias, act=None):
+        for t in (weight, bias) + ((act,) if act is not None else ()):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise Lic360Error("codec parameters must be contiguous float32 device tensors")
+        _chk(_lib.lic360_codec_set_layer(_stream(self.device), self._h, int(layer), _p(weight), _p(bias), _p(act)))
+
+    def load_from_driver(self, drv):
+        """Take the 12 batched layers of an EntEncoderFast / EntDecoder (state_dict keys net.N.*)."""
+        mods = [drv.net[0]]
+        for i in range(1, 6):
+            mods += [drv.net[i].conv1, drv.net[i].conv2]
+        mods.append(drv.net[6])
+        for i, m in enumerate(mods):
+            self.set_layer(i, m.weight.data.contiguous(), m.bias.data.contiguous(), None if m.relu is None else m.relu.data.contiguous())
+
+    def load_layers(self, layers):
+        """layers: list of 12 dicts with numpy/torch 'w' [3,nout,C,5,5], 'b' [3,nout], 'a' [3,nout] or None."""
+        dev = "cuda:%d" % self.device
+        to = lambda a: None if a is None else torch.as_tensor(a).to(dev).contiguous()
+        for i, l in enumerate(layers):
+            self.set_layer(i, to(l["w"]), to(l["b"]), to(l["a"]))
+        torch.cuda.synchronize(self.device)
+
+    # ---- codec ---------------------------------------------------------------------------------------
+    def _check(self, t, name):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape[1:]) == (self.G, self.H, self.W)
+                and 0 < t.shape[0] <= self.maxB):
+            raise Lic360Error("%s must be a contiguous float32 device tensor [b<=%d,%d,%d,%d]" % (name, self.maxB, self.G, self.H, self.W))
+
+    def encode_async(self, code, mask):
+        """Queue the encode of a batch; results land in self.bytes / self.nbytes / self.err (device)."""
+        self._check(code, "code")
+        self._check(mask, "mask")
+        b = code.shape[0]
+        _chk(_lib.lic360_codec_encode(_stream(self.device), self._h, _p(code), _p(mask), b, _p(self.bytes), C.c_long(self.cap),
+                                      _p(self.nbytes), _p(self.err)))
+        return b
+
+    def decode_async(self, mask, b=None, bytes_dev=None, nbytes_dev=None):
+        self._check(mask, "mask")
+        b = mask.shape[0] if b is None else b
+        bd = self.bytes if bytes_dev is None else bytes_dev
+        nd = self.nbytes if nbytes_dev is None else nbytes_dev
+        _chk(_lib.lic360_codec_decode(_stream(self.device), self._h, _p(bd), C.c_long(bd.shape[1]), _p(nd), _p(mask), b,
+                                      _p(self.code_out), _p(self.err)))
+        return self.code_out[:b]
+
+    def encode(self, code, mask):
+        """-> list of `bytes`, one bitstream per image (what the reference writes to `<code>`)."""
+        b = self.encode_async(code, mask)
+        nb = self.nbytes[:b].cpu().tolist()
+        er = self.err[:b].cpu().tolist()
+        if any(er):
+            raise Lic360Error("arithmetic encoder fault / capacity overflow: %s" % er)
+        host = self.bytes[:b].cpu()
+        return [bytes(host[i, :nb[i]].numpy().tobytes()) for i in range(b)]
+
+    def decode(self, streams, mask):
+        b = len(streams)
+        host = torch.zeros((self.maxB, self.cap), dtype=torch.uint8)
+        nb = torch.zeros((self.maxB,), dtype=torch.int32)
+        for i, s in enumerate(streams):
+            if len(s) > self.cap:
+                raise Lic360Error("bitstream %d longer than the codec capacity" % i)
+            host[i, :len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8)
+            nb[i] = len(s)
+        self.bytes.copy_(host)
+        self.nbytes.copy_(nb)
+        out = self.decode_async(mask, b).clone()
+        if int(self.err[:b].abs().sum().item()):
+            raise Lic360Error("arithmetic decoder fault (corrupt stream?): %s" % self.err[:b].cpu().tolist())
+        return out

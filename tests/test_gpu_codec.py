@@ -75,3 +75,25 @@ def test_cast_entropy_parameter():
             assert torch.all(v[idx] == idx + 1), k
     assert set(out.keys()) == {"net.0.weight", "net.0.bias", "net.0.relu", "net.6.weight", "net.6.bias"} | {
         "net.%d.%s.%s" % (b, c, p) for b in range(1, 6) for c in ("conv1", "conv2") for p in ("weight", "bias", "relu")}
+
+
+@pytest.mark.parametrize("G,H,W,B,seed", [(6, 8, 12, 3, 11), (8, 6, 10, 1, 12), (48, 8, 16, 2, 13)])
+def test_fused_codec_matches_oracle(G, H, W, B, seed):
+    """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode."""
+    from lic360_fused import FusedCodec
+    rng = np.random.default_rng(seed)
+    layers = rc.make_main_params(2000 + seed, G)
+    items = [latent(rng, G, H, W) for _ in range(B)]
+    code = np.concatenate([it[0] for it in items], 0)
+    mask = np.concatenate([it[1] for it in items], 0)
+    if B > 1:
+        mask[1] = 0.0                      # one fully masked image -> bare terminator byte
+    fc = FusedCodec(G, H, W, max_batch=4)
+    fc.load_layers(layers)
+    streams = fc.encode(dev(code), dev(mask))
+    for i in range(B):
+        assert streams[i] == rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G), "image %d" % i
+    if B > 1:
+        assert streams[1] == b"\x80"
+    out = fc.decode(streams, dev(mask)).cpu().numpy()
+    assert np.array_equal(out, code * mask)
