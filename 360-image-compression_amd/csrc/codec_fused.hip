@@ -35,7 +35,22 @@ struct lic360_codec {
     float *d_x0, *d_act[11], *d_y;
     AcDevState *d_state;
     bool layer_set[12];
+    // optional per-kernel timing of the hidden-layer conv launches (bench.py roofline leg)
+    bool prof = false;
+    std::vector<hipEvent_t> ev_ec, ev_dc;      // start/stop pairs
+    size_t n_ec = 0, n_dc = 0;
 };
+
+static int prof_mark(lic360_codec *c, std::vector<hipEvent_t> &pool, size_t &n, hipStream_t s) {
+    if (!c->prof) return 0;
+    if (n >= pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        pool.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(pool[n++], s));
+    return 0;
+}
 
 static int plan_of(int layer) { return layer == 0 ? 0 : (layer == 11 ? 2 : 1); }
 
@@ -304,8 +319,12 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     if (lic360_cconv_ec_ex(stream, c->plan[0], c->e_x0, c->packed[0], c->bias[0], c->act[0], nullptr, cur, 3 * B, H, W, 3, B)) return 1;
     for (int blk = 0; blk < 5; ++blk) {
         int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
+        prof_mark(c, c->ev_ec, c->n_ec, s);
         if (lic360_cconv_ec_ex(stream, c->plan[1], cur, c->packed[a], c->bias[a], c->act[a], nullptr, t1, 3 * B, H, W, 3, 3 * B)) return 1;
+        prof_mark(c, c->ev_ec, c->n_ec, s);
+        prof_mark(c, c->ev_ec, c->n_ec, s);
         if (lic360_cconv_ec_ex(stream, c->plan[1], t1, c->packed[b2], c->bias[b2], c->act[b2], cur, nxt, 3 * B, H, W, 3, 3 * B)) return 1;
+        prof_mark(c, c->ev_ec, c->n_ec, s);
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (lic360_cconv_ec_ex(stream, c->plan[2], cur, c->packed[11], c->bias[11], nullptr, nullptr, t1, 3 * B, H, W, 3, 3 * B)) return 1;
@@ -332,10 +351,14 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
                                      c->d_idx, c->d_pidx, pih, p, B, 1)) return 1;
         for (int blk = 0; blk < 5; ++blk) {
             int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
+            prof_mark(c, c->ev_dc, c->n_dc, s);
             if (lic360_cconv_dc_plane_ex(stream, c->plan[1], c->d_act[a - 1], c->packed[a], c->bias[a], c->act[a], nullptr, c->d_act[a],
                                          3 * B, H, W, 3, c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+            prof_mark(c, c->ev_dc, c->n_dc, s);
+            prof_mark(c, c->ev_dc, c->n_dc, s);
             if (lic360_cconv_dc_plane_ex(stream, c->plan[1], c->d_act[a], c->packed[b2], c->bias[b2], c->act[b2], c->d_act[a - 1], c->d_act[b2],
                                          3 * B, H, W, 3, c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+            prof_mark(c, c->ev_dc, c->n_dc, s);
         }
         if (lic360_cconv_dc_plane_ex(stream, c->plan[2], c->d_act[10], c->packed[11], c->bias[11], nullptr, nullptr, c->d_y, 3 * B, H, W, 3,
                                      c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
@@ -347,5 +370,34 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
     LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ timing hooks
+LIC360_API int lic360_codec_profile_enable(lic360_codec *c, int on) {
+    ARG_CHECK(c);
+    c->prof = on != 0;
+    c->n_ec = c->n_dc = 0;
+    return 0;
+}
+
+// Sum of HIP-event elapsed times (ms) and launch counts of the hidden-layer conv kernels recorded since the
+// last call; the events were recorded on the stream the kernels ran on.  Synchronises on the last event.
+LIC360_API int lic360_codec_profile_read(lic360_codec *c, double *ec_ms, long *ec_launches, double *dc_ms, long *dc_launches) {
+    ARG_CHECK(c && ec_ms && ec_launches && dc_ms && dc_launches);
+    double acc[2] = {0, 0};
+    std::vector<hipEvent_t> *pools[2] = {&c->ev_ec, &c->ev_dc};
+    size_t cnt[2] = {c->n_ec, c->n_dc};
+    for (int k = 0; k < 2; ++k) {
+        for (size_t i = 0; i + 1 < cnt[k]; i += 2) {
+            HIP_TRY(hipEventSynchronize((*pools[k])[i + 1]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, (*pools[k])[i], (*pools[k])[i + 1]));
+            acc[k] += ms;
+        }
+    }
+    *ec_ms = acc[0]; *ec_launches = (long)(cnt[0] / 2);
+    *dc_ms = acc[1]; *dc_launches = (long)(cnt[1] / 2);
+    c->n_ec = c->n_dc = 0;
     return 0;
 }

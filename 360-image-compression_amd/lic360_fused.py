@@ -111,3 +111,13 @@ class FusedCodec(object):
         if int(self.err[:b].abs().sum().item()):
             raise Lic360Error("arithmetic decoder fault (corrupt stream?): %s" % self.err[:b].cpu().tolist())
         return out
+
+    # ---- timing hooks (bench.py) ---------------------------------------------------------------------
+    def profile(self, on=True):
+        _chk(_lib.lic360_codec_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ec, dc = C.c_double(0), C.c_double(0)
+        nec, ndc = C.c_long(0), C.c_long(0)
+        _chk(_lib.lic360_codec_profile_read(self._h, C.byref(ec), C.byref(nec), C.byref(dc), C.byref(ndc)))
+        return dict(ec_ms=ec.value, ec_launches=nec.value, dc_ms=dc.value, dc_launches=ndc.value)

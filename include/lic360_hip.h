@@ -160,6 +160,11 @@ int lic360_codec_encode(void *stream, lic360_codec *codec, const float *code, co
 int lic360_codec_decode(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
                         const float *mask, int b, float *code_out, int *err);
 
+/* timing hooks for bench.py: HIP events around every hidden-layer conv launch (encode-order / decode-order),
+ * recorded on the caller's stream; read() returns the summed elapsed ms + launch counts and resets */
+int lic360_codec_profile_enable(lic360_codec *codec, int on);
+int lic360_codec_profile_read(lic360_codec *codec, double *ec_ms, long *ec_launches, double *dc_ms, long *dc_launches);
+
 #ifdef __cplusplus
 }
 #endif
