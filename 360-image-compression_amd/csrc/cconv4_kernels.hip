@@ -1,0 +1,359 @@
+// cconv4_kernels.hip -- "leaf-resident" group-causal masked convolution for the latent entropy nets
+// (A9/A10 for the shapes test/lic360_demo.py:104-112 uses: ngroup groups, cin in {1,4}, cout in {3,4}).
+//
+// Same arithmetic contract as cconv_kernels.hip (extension/cconv_ec_cuda.cu:268-315: one fmaf chain per
+// virtual lane over ti = gid, gid+cin, ...; then the fixed 128-leaf tree), different mapping:
+//
+//   * 64 output positions of ONE output group g (its <=4 output channels) are owned by FOUR waves; wave c
+//     keeps the partial sums of the virtual lanes l = c (mod 4) resident in registers, one 4x4x1 MFMA
+//     accumulator per lane (4 output channels x this thread's position).  Because 25 = 1 (mod 4), for
+//     cin = 4 every wave gets exactly one lane per tap (gid = (c - tap) mod 4): 25 accumulators, 100 VGPRs;
+//   * the K loop runs over the input GROUP index tc (outermost), so a step needs only the cin channels of
+//     group tc: they are staged in LDS once per step and shared by all taps, rows and lane classes; the
+//     chain of lane (gid,kh,kw) receives exactly its own terms tc = 0..L-1 in order, i.e. the reference's
+//     fmaf chain with NO padding work (v_mfma_f32_4x4x1_16b_f32 has K = 1: D = fma(A, B, C), measured
+//     bit-exact on gfx950, tools/mfma_probe.hip);
+//   * the 4 weights of a lane (one per output channel) sit in lanes 0-3 of the A operand and are broadcast
+//     to all 16 4x4 blocks with cbsz = 4; one ds_read_b128 fetches them for 4 taps;
+//   * causality removes whole taps per step (lane active iff kh+kw < g+4+hidden-tc): one scalar branch per tap;
+//   * lanes of equal index mod 4 stay together until the last two levels of the reference's tree
+//     (p[i]+p[i+64], +32, ..., +4 happen inside a class), so each wave reduces its own 25 accumulators in
+//     registers and only ONE tile per wave crosses LDS for the final (F0+F2)+(F1+F3).
+//
+// Encode order (EC4): workgroup = 12 waves = 3 consecutive rows x 64 columns of one (sample, group); the
+// 7 x 68 halo tile of the step's cin channels and the step's 2 KB of weights are double-buffered in LDS.
+// Decode order (DC4): workgroup = 12 waves = 3 adjacent groups (adjacent anti-diagonals of the current
+// plane) of one sample; lanes run along the diagonal in a diagonal-major activation layout
+// [n][c][th+tw][th], so the 11 x 71 halo band (shared by the 3 diagonals) loads and the output stores are
+// contiguous.
+#include "common.h"
+#include "conv_plan.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define C4_COLS 68                       // 64 positions + 2*2 halo
+#define C4_WSLOTS 128                    // weight slots per step (>= 25*cin), 4 floats each
+
+static inline bool conv4_ok(const lic360_conv_plan *p) {
+    return p->ksz == 5 && (p->cin == 1 || p->cin == 4) && p->cout >= 1 && p->cout <= 4 && p->ngroup <= 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed4[net][g][tc][c][tq][r][j]: class c = virtual lane mod 4, leaf i = tq*4+j inside the class
+// (cin = 4: tap = i, gid = (c - tap) mod 4;  cin = 1: tap = c + 4*i), r = output channel within the group
+__global__ void k_conv4_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int ngroup, int cin, int cout, int hidden) {
+    const long per_net = (long)ngroup * ngroup * C4_WSLOTS * 4, total = per_net * nb;
+    const int C = ngroup * cin, nout = ngroup * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int j = (int)(i & 3), r = (int)((i >> 2) & 3), tq = (int)((i >> 4) & 7), c = (int)((i >> 7) & 3);
+        long t = i / (C4_WSLOTS * 4);
+        int tc = (int)(t % ngroup), g = (int)((t / ngroup) % ngroup), b = (int)(t / ((long)ngroup * ngroup));
+        int leaf = tq * 4 + j;
+        int tap = cin == 4 ? leaf : c + 4 * leaf, gid = cin == 4 ? ((c - tap) & 3) : 0;
+        float v = 0.0f;
+        if (tap < 25 && r < cout) {
+            int kh = tap / 5, kw = tap % 5;
+            int L = g + 4 - kh - kw + hidden;               // chain length of this lane (extension/cconv_ec_cuda.cu:288-290)
+            if (L > ngroup) L = ngroup;
+            if (tc < L) v = weight[(((long)b * nout + g * cout + r) * C + tc * cin + gid) * 25 + tap];
+        }
+        packed[i] = v;
+    }
+}
+
+LIC360_API int lic360_conv4_supported(const lic360_conv_plan *p) { return p && conv4_ok(p) ? 1 : 0; }
+LIC360_API long lic360_conv4_packed_floats(const lic360_conv_plan *p) {
+    return p && conv4_ok(p) ? (long)p->ngroup * p->ngroup * C4_WSLOTS * 4 : 0;
+}
+LIC360_API int lic360_conv4_pack(void *stream, const lic360_conv_plan *p, const float *weight, int nb, float *packed) {
+    ARG_CHECK(p && conv4_ok(p) && weight && packed && nb > 0);
+    long total = lic360_conv4_packed_floats(p) * nb;
+    hipLaunchKernelGGL(k_conv4_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, nb, p->ngroup, p->cin,
+                       p->cout, p->constrain == 5 ? 0 : 1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the reference's reduction tree on registers: F(i, 128) = p[i];  F(i, s) = F(i, 2s) + F(i + s, 2s);  result F(0, 1)
+// (p[i] + p[i+64] first, ..., + p[i+1] last; cconv_ec_cuda.cu:299-309).  A wave of class c evaluates F(c, 4).
+// Lane i of class c = i%4 lives in accumulator i%25 (cin = 4) or i/4 (cin = 1).
+template <int CIN, int I, int S>
+struct Tree4 {
+    static constexpr bool live = Tree4<CIN, I, S * 2>::live || Tree4<CIN, I + S, S * 2>::live;
+    static __device__ __forceinline__ f32x4 eval(const f32x4 *acc) {
+        if constexpr (!Tree4<CIN, I + S, S * 2>::live) return Tree4<CIN, I, S * 2>::eval(acc);     // x + 0 == x
+        else if constexpr (!Tree4<CIN, I, S * 2>::live) return Tree4<CIN, I + S, S * 2>::eval(acc);
+        else return Tree4<CIN, I, S * 2>::eval(acc) + Tree4<CIN, I + S, S * 2>::eval(acc);
+    }
+};
+template <int CIN, int I>
+struct Tree4<CIN, I, 128> {
+    static constexpr bool live = I < 25 * CIN;
+    static __device__ __forceinline__ f32x4 eval(const f32x4 *acc) {
+        if constexpr (live) return acc[CIN == 4 ? I % 25 : I / 4];
+        else return (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+};
+
+template <int CIN> struct NAcc { static constexpr int value = CIN == 4 ? 25 : 7; };
+
+// one K step of lane class CLS: every active lane gets  acc = fma(w, x, acc).
+// DIAG: staged tile rows are anti-diagonals (row = kh+kw, col = kh + lane) instead of image rows (row = kh, col = kw + lane).
+template <int CIN, int CLS, int XPLANE, int COLS, bool DIAG>
+__device__ __forceinline__ void conv4_step(f32x4 *acc, const float *xs, const f32x4 *ws4, int dlim, int lane, int xbase) {
+#pragma unroll
+    for (int i = 0; i < NAcc<CIN>::value; ++i) {
+        const int tap = CIN == 4 ? i : CLS + 4 * i;
+        if (tap < 25) {
+            const int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
+            if (kh + kw < dlim) {
+                const f32x4 a4 = ws4[(CLS * 8 + i / 4) * 4 + (lane & 3)];
+                const float bv = xs[xbase + gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
+                acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[i % 4], bv, acc[i], 4, 0, 0);
+            }
+        }
+    }
+}
+
+#define C4_PS 3                          // position sets (rows / diagonals) per workgroup
+#define C4_THREADS (C4_PS * 4 * 64)      // 12 waves: 3 per SIMD -> 168 VGPRs each, no spills with 25 resident accumulators
+// final two tree levels across the 4 lane classes of a position set + epilogue handled by the caller
+#define C4_COMB_FLOATS (C4_PS * 4 * 4 * 64)
+
+// ------------------------------------------------------------------------------------------------ EC4
+#define EC4_ROWS (C4_PS + 4)              // output rows + 2*2 halo
+template <int CIN, int CLS>
+__device__ __forceinline__ f32x4 ec4_body(const float *__restrict__ xn, const f32x4 *__restrict__ wp, float (*xs)[CIN * EC4_ROWS * C4_COLS],
+                                          f32x4 (*ws4)[C4_WSLOTS], int tid, int lane, int ps, int g, int hidden, int Lmax,
+                                          int r0, int c0, int H, int W) {
+    constexpr int XPLANE = EC4_ROWS * C4_COLS, XS = CIN * XPLANE;
+    constexpr int XLD = (XS + C4_THREADS - 1) / C4_THREADS;
+    f32x4 acc[NAcc<CIN>::value];
+#pragma unroll
+    for (int i = 0; i < NAcc<CIN>::value; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float xr[XLD];
+    f32x4 wr = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int tc) {
+#pragma unroll
+        for (int k = 0; k < XLD; ++k) {
+            int e = tid + k * C4_THREADS;
+            float v = 0.0f;
+            if (e < XS) {
+                int gid = e / XPLANE, q = e % XPLANE, rr = q / C4_COLS, cc = q % C4_COLS;
+                int gr = r0 - 2 + rr, gc = c0 - 2 + cc;
+                if (gr >= 0 && gr < H && gc >= 0 && gc < W) v = xn[((long)(tc * CIN + gid) * H + gr) * W + gc];
+            }
+            xr[k] = v;
+        }
+        if (tid < C4_WSLOTS) wr = wp[(long)tc * C4_WSLOTS + tid];
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < XLD; ++k) {
+            int e = tid + k * C4_THREADS;
+            if (e < XS) xs[buf][e] = xr[k];
+        }
+        if (tid < C4_WSLOTS) ws4[buf][tid] = wr;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int xbase = ps * C4_COLS + lane;
+    for (int tc = 0; tc < Lmax; ++tc) {
+        const int cur = tc & 1, dlim = g + 4 + hidden - tc;
+        if (tc + 1 < Lmax) gload(tc + 1);
+        conv4_step<CIN, CLS, XPLANE, C4_COLS, false>(acc, xs[cur], ws4[cur], dlim, lane, xbase);
+        if (tc + 1 < Lmax) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    return Tree4<CIN, CLS, 4>::eval(acc);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(C4_THREADS) void k_cconv4_ec(
+    const float *__restrict__ x, const float *__restrict__ packed, const float *__restrict__ bias, const float *__restrict__ act,
+    const float *__restrict__ residual, float *__restrict__ out, int ngroup, int cout, int hidden, int H, int W, int npb, int x_mod) {
+    constexpr int XS = CIN * EC4_ROWS * C4_COLS;
+    __shared__ float xs[2][XS];
+    __shared__ f32x4 ws4[2][C4_WSLOTS];
+    __shared__ float comb[C4_COMB_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), ps = wave >> 2, cls = wave & 3;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * C4_PS;
+    const int g = blockIdx.z % ngroup, n = blockIdx.z / ngroup, nbatch = n / npb;
+    const int C = ngroup * CIN, nout = ngroup * cout;
+    int Lmax = g + 4 + hidden;
+    if (Lmax > ngroup) Lmax = ngroup;
+    const float *xn = x + (long)(n % x_mod) * C * H * W;
+    const f32x4 *wp = (const f32x4 *)(packed + (((long)nbatch * ngroup + g) * ngroup) * C4_WSLOTS * 4);
+    f32x4 part;
+    // every wave runs the same number of barriers; the four lane classes differ only in compile-time offsets
+    switch (cls) {
+        case 0: part = ec4_body<CIN, 0>(xn, wp, xs, ws4, tid, lane, ps, g, hidden, Lmax, r0, c0, H, W); break;
+        case 1: part = ec4_body<CIN, 1>(xn, wp, xs, ws4, tid, lane, ps, g, hidden, Lmax, r0, c0, H, W); break;
+        case 2: part = ec4_body<CIN, 2>(xn, wp, xs, ws4, tid, lane, ps, g, hidden, Lmax, r0, c0, H, W); break;
+        default: part = ec4_body<CIN, 3>(xn, wp, xs, ws4, tid, lane, ps, g, hidden, Lmax, r0, c0, H, W); break;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) comb[((ps * 4 + cls) * 4 + r) * 64 + lane] = part[r];
+    __syncthreads();
+    // wave (ps, cls) finishes output channel r = cls of its position set: (F0 + F2) + (F1 + F3)
+    const int r = cls;
+    const int gr = r0 + ps, gc = c0 + lane;
+    if (r < cout && gr < H && gc < W) {
+        const float f0 = comb[((ps * 4 + 0) * 4 + r) * 64 + lane], f1 = comb[((ps * 4 + 1) * 4 + r) * 64 + lane];
+        const float f2 = comb[((ps * 4 + 2) * 4 + r) * 64 + lane], f3 = comb[((ps * 4 + 3) * 4 + r) * 64 + lane];
+        const int o = g * cout + r, bid = nbatch * nout + o;
+        float sv = ((f0 + f2) + (f1 + f3)) + bias[bid];
+        if (act) sv = sv > 0 ? sv : sv * act[bid];                      // cconv_ec_cuda.cu:311-312
+        const long oi = (((long)n * nout + o) * H + gr) * W + gc;
+        if (residual) sv = sv + residual[oi];
+        out[oi] = sv;
+    }
+}
+
+LIC360_API int lic360_cconv4_ec(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod) {
+    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
+    ARG_CHECK((long)n * p->ngroup < 65536);
+    dim3 grid((w + 63) / 64, (h + C4_PS - 1) / C4_PS, n * p->ngroup);
+    const int hidden = p->constrain == 5 ? 0 : 1;
+    if (p->cin == 4)
+        hipLaunchKernelGGL(k_cconv4_ec<4>, grid, dim3(C4_THREADS), 0, (hipStream_t)stream, x, packed4, bias, act, residual, out, p->ngroup,
+                           p->cout, hidden, h, w, n / nb, x_mod);
+    else
+        hipLaunchKernelGGL(k_cconv4_ec<1>, grid, dim3(C4_THREADS), 0, (hipStream_t)stream, x, packed4, bias, act, residual, out, p->ngroup,
+                           p->cout, hidden, h, w, n / nb, x_mod);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ DC4
+// Activations in diagonal-major layout [n][c][s = th+tw][th] (S = H+W-1 diagonals of H slots).
+// Workgroup = groups g0..g0+PS-1 (anti-diagonals s0, s0-1, .. with s0 = psum - g0) of one sample.
+// Staged band: band[gid][row][col] = x[ch][(th, tw)] with th + tw = s0 - (PS-1) - 4 + row, th = th_base - 2 + col,
+// th_base = first row index of the lowest diagonal (s0 - (PS-1)).
+#define DC4_ROWS (9 + C4_PS - 1)
+#define DC4_COLS (68 + C4_PS - 1 + 1)
+template <int CIN, int CLS>
+__device__ __forceinline__ f32x4 dc4_body(const float *__restrict__ xn, const f32x4 *__restrict__ packed4, float (*xs)[CIN * DC4_ROWS * DC4_COLS],
+                                          f32x4 (*ws4)[C4_PS * C4_WSLOTS], int tid, int lane, int ps, int g0, int g, bool glive, int hidden,
+                                          int Lwg, int s0, int th_base, int th_lo, int nbatch, int ngroup, int H, int W) {
+    constexpr int XPLANE = DC4_ROWS * DC4_COLS, XS = CIN * XPLANE;
+    constexpr int XLD = (XS + C4_THREADS - 1) / C4_THREADS;
+    const int S = H + W - 1;
+    const long SK = (long)S * H;
+    f32x4 acc[NAcc<CIN>::value];
+#pragma unroll
+    for (int i = 0; i < NAcc<CIN>::value; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float xr[XLD];
+    f32x4 wr = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int tc) {
+        const int rlim = g0 + (C4_PS - 1) + 4 + hidden - tc;            // band rows >= rlim are not read in this step
+#pragma unroll
+        for (int k = 0; k < XLD; ++k) {
+            int e = tid + k * C4_THREADS;
+            float v = 0.0f;
+            if (e < XS) {
+                int gid = e / XPLANE, q = e % XPLANE, row = q / DC4_COLS, col = q % DC4_COLS;
+                int sp = s0 - (C4_PS - 1) - 4 + row, thp = th_base - 2 + col, twp = sp - thp;
+                if (row < rlim && sp >= 0 && sp < S && thp >= 0 && thp < H && twp >= 0 && twp < W)
+                    v = xn[(long)(tc * CIN + gid) * SK + (long)sp * H + thp];
+            }
+            xr[k] = v;
+        }
+        if (tid < C4_PS * C4_WSLOTS) {
+            int gg = g0 + (tid >> 7);
+            wr = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (gg < ngroup) wr = packed4[(((long)nbatch * ngroup + gg) * ngroup + tc) * C4_WSLOTS + (tid & 127)];
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < XLD; ++k) {
+            int e = tid + k * C4_THREADS;
+            if (e < XS) xs[buf][e] = xr[k];
+        }
+        if (tid < C4_PS * C4_WSLOTS) ws4[buf][tid] = wr;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    // tap (kh,kw) of the position `lane` on diagonal s: band row (s + kh+kw-4) - (s0-(PS-1)-4) = (PS-1-ps) + kh+kw, col (th_lo+lane+kh-2) - (th_base-2)
+    const int xbase = (C4_PS - 1 - ps) * DC4_COLS + (glive ? th_lo - th_base : 0) + lane;
+    for (int tc = 0; tc < Lwg; ++tc) {
+        const int cur = tc & 1, dlim = glive ? g + 4 + hidden - tc : 0;
+        if (tc + 1 < Lwg) gload(tc + 1);
+        conv4_step<CIN, CLS, XPLANE, DC4_COLS, true>(acc, xs[cur], ws4[cur] + ps * C4_WSLOTS, dlim, lane, xbase);
+        if (tc + 1 < Lwg) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    return Tree4<CIN, CLS, 4>::eval(acc);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(C4_THREADS) void k_cconv4_dc(
+    const float *__restrict__ x, const float *__restrict__ packed, const float *__restrict__ bias, const float *__restrict__ act,
+    const float *__restrict__ residual, float *__restrict__ out, int ngroup, int cout, int hidden, int H, int W, int npb, int x_mod,
+    int psum) {
+    constexpr int XS = CIN * DC4_ROWS * DC4_COLS;
+    __shared__ float xs[2][XS];
+    __shared__ f32x4 ws4[2][C4_PS * C4_WSLOTS];
+    __shared__ float comb[C4_COMB_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), ps = wave >> 2, cls = wave & 3;
+    const int g0 = blockIdx.x * C4_PS, n = blockIdx.y, nbatch = n / npb;
+    const int S = H + W - 1;
+    const int s0 = psum - g0;                                           // diagonal of group g0; group g0+k sits on s0-k
+    if (s0 - (C4_PS - 1) >= S || s0 < 0) return;                        // no group of this block is on the plane
+    const int g = g0 + ps, s = s0 - ps;
+    const bool glive = g < ngroup && s >= 0 && s < S;
+    const int sb = s0 - (C4_PS - 1) > 0 ? s0 - (C4_PS - 1) : 0;
+    const int th_base = sb >= W ? sb - W + 1 : 0;
+    const int th_lo = glive ? (s >= W ? s - W + 1 : 0) : 0, th_hi = glive ? (s < H ? s : H - 1) : -1;
+    const int C = ngroup * CIN, nout = ngroup * cout;
+    int Lwg = g0 + (C4_PS - 1) + 4 + hidden;                            // longest chain in the block
+    if (Lwg > ngroup) Lwg = ngroup;
+    const long SK = (long)S * H;
+    const float *xn = x + (long)(n % x_mod) * C * SK;
+    const f32x4 *p4 = (const f32x4 *)packed;
+    f32x4 part;
+    switch (cls) {
+        case 0: part = dc4_body<CIN, 0>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
+        case 1: part = dc4_body<CIN, 1>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
+        case 2: part = dc4_body<CIN, 2>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
+        default: part = dc4_body<CIN, 3>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) comb[((ps * 4 + cls) * 4 + r) * 64 + lane] = part[r];
+    __syncthreads();
+    const int r = cls, th = th_lo + lane;
+    if (glive && r < cout && th <= th_hi) {
+        const float f0 = comb[((ps * 4 + 0) * 4 + r) * 64 + lane], f1 = comb[((ps * 4 + 1) * 4 + r) * 64 + lane];
+        const float f2 = comb[((ps * 4 + 2) * 4 + r) * 64 + lane], f3 = comb[((ps * 4 + 3) * 4 + r) * 64 + lane];
+        const int o = g * cout + r, bid = nbatch * nout + o;
+        float sv = ((f0 + f2) + (f1 + f3)) + bias[bid];
+        if (act) { if (sv < 0) sv = sv * act[bid]; }                    // cconv_dc_cuda.cu:360-362
+        const long oi = ((long)n * nout + o) * SK + (long)s * H + th;
+        if (residual) sv = sv + residual[oi];                           // fused TileAdd
+        out[oi] = sv;
+    }
+}
+
+LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                      const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
+    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
+    ARG_CHECK(h <= 64 || w <= 64);                                      // an anti-diagonal must fit one wave (64 positions)
+    if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
+    const int hidden = p->constrain == 5 ? 0 : 1;
+    dim3 grid((p->ngroup + C4_PS - 1) / C4_PS, n, 1);
+    if (p->cin == 4)
+        hipLaunchKernelGGL(k_cconv4_dc<4>, grid, dim3(C4_THREADS), 0, (hipStream_t)stream, x, packed4, bias, act, residual, out, p->ngroup,
+                           p->cout, hidden, h, w, n / nb, x_mod, psum);
+    else
+        hipLaunchKernelGGL(k_cconv4_dc<1>, grid, dim3(C4_THREADS), 0, (hipStream_t)stream, x, packed4, bias, act, residual, out, p->ngroup,
+                           p->cout, hidden, h, w, n / nb, x_mod, psum);
+    LAUNCH_CHECK();
+    return 0;
+}

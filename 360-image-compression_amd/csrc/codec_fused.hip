@@ -28,6 +28,8 @@ struct lic360_codec {
     int G, H, W, maxB, S, P, HW;
     lic360_conv_plan *plan[3];                 // first, hidden, last
     float *packed[12], *bias[12], *act[12];
+    float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
+    bool use4;
     std::vector<int> h_idx, h_pidx, h_plane_start;
     int *d_idx, *d_pidx, *d_plane_start;
     float *e_x0, *e_buf[3];
@@ -228,12 +230,15 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     lic360_codec *c = new lic360_codec();
     memset(c->layer_set, 0, sizeof(c->layer_set));
     c->G = ngroup; c->H = h; c->W = w; c->maxB = max_batch; c->S = h + w - 1; c->P = h + w + ngroup - 2; c->HW = h * w;
-    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = nullptr;
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = nullptr;
     int rc = 0;
     rc |= lic360_conv_plan_create(ngroup * 1, ngroup, ngroup * 4, 5, 5, &c->plan[0]);
     rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 4, 5, 6, &c->plan[1]);
     rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 3, 5, 6, &c->plan[2]);
     if (rc) return 1;
+    const char *force = getenv("LIC360_FUSED_CONV");                  // "16" forces the 16x16x4 kernels (A/B comparisons)
+    c->use4 = lic360_conv4_supported(c->plan[0]) && lic360_conv4_supported(c->plan[1]) && lic360_conv4_supported(c->plan[2]) &&
+              (h <= 64 || w <= 64) && !(force && force[0] == '1' && force[1] == '6');
     c->h_idx.resize(2 * (size_t)c->HW);
     c->h_pidx.resize(h + w);
     lic360_code_contex(h, w, c->h_idx.data(), c->h_pidx.data());
@@ -274,7 +279,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
 LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     if (!c) return;
     for (int i = 0; i < 3; ++i) lic360_conv_plan_destroy(c->plan[i]);
-    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); }
+    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); (void)hipFree(c->packed4[i]); }
     (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->d_plane_start);
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
@@ -291,8 +296,10 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
         if (dmalloc(&c->packed[layer], 3 * (size_t)nper)) return 1;
         if (dmalloc(&c->bias[layer], 3 * (size_t)p->nout)) return 1;
         if (act && dmalloc(&c->act[layer], 3 * (size_t)p->nout)) return 1;
+        if (c->use4 && dmalloc(&c->packed4[layer], 3 * (size_t)lic360_conv4_packed_floats(p))) return 1;
     }
     if (lic360_conv_pack(stream, p, weight, 3, c->packed[layer])) return 1;
+    if (c->use4 && lic360_conv4_pack(stream, p, weight, 3, c->packed4[layer])) return 1;
     HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->layer_set[layer] = true;
@@ -316,18 +323,23 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total);
     LAUNCH_CHECK();
     float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
-    if (lic360_cconv_ec_ex(stream, c->plan[0], c->e_x0, c->packed[0], c->bias[0], c->act[0], nullptr, cur, 3 * B, H, W, 3, B)) return 1;
+    auto ec = [&](int layer, const float *xin, const float *res, float *dst, int x_mod) -> int {
+        lic360_conv_plan *p = c->plan[plan_of(layer)];
+        if (c->use4) return lic360_cconv4_ec(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
+        return lic360_cconv_ec_ex(stream, p, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
+    };
+    if (ec(0, c->e_x0, nullptr, cur, B)) return 1;
     for (int blk = 0; blk < 5; ++blk) {
         int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
         prof_mark(c, c->ev_ec, c->n_ec, s);
-        if (lic360_cconv_ec_ex(stream, c->plan[1], cur, c->packed[a], c->bias[a], c->act[a], nullptr, t1, 3 * B, H, W, 3, 3 * B)) return 1;
+        if (ec(a, cur, nullptr, t1, 3 * B)) return 1;
         prof_mark(c, c->ev_ec, c->n_ec, s);
         prof_mark(c, c->ev_ec, c->n_ec, s);
-        if (lic360_cconv_ec_ex(stream, c->plan[1], t1, c->packed[b2], c->bias[b2], c->act[b2], cur, nxt, 3 * B, H, W, 3, 3 * B)) return 1;
+        if (ec(b2, t1, cur, nxt, 3 * B)) return 1;
         prof_mark(c, c->ev_ec, c->n_ec, s);
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
-    if (lic360_cconv_ec_ex(stream, c->plan[2], cur, c->packed[11], c->bias[11], nullptr, nullptr, t1, 3 * B, H, W, 3, 3 * B)) return 1;
+    if (ec(11, cur, nullptr, t1, 3 * B)) return 1;
     hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx, c->d_plane_start,
                        c->e_rec, B, G, H, W);
     LAUNCH_CHECK();
@@ -345,23 +357,25 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
     LAUNCH_CHECK();
     const int *pih = c->h_pidx.data();
+    auto dc = [&](int layer, const float *xin, const float *res, float *dst, int x_mod, int p) -> int {
+        lic360_conv_plan *pl = c->plan[plan_of(layer)];
+        if (c->use4) return lic360_cconv4_dc_plane(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
+        return lic360_cconv_dc_plane_ex(stream, pl, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3,
+                                        c->d_idx, c->d_pidx, pih, p, x_mod, 1);
+    };
     for (int p = 0; p < c->P; ++p) {
         // plane p of all 12 layers (x0 already holds planes < p)
-        if (lic360_cconv_dc_plane_ex(stream, c->plan[0], c->d_x0, c->packed[0], c->bias[0], c->act[0], nullptr, c->d_act[0], 3 * B, H, W, 3,
-                                     c->d_idx, c->d_pidx, pih, p, B, 1)) return 1;
+        if (dc(0, c->d_x0, nullptr, c->d_act[0], B, p)) return 1;
         for (int blk = 0; blk < 5; ++blk) {
             int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
             prof_mark(c, c->ev_dc, c->n_dc, s);
-            if (lic360_cconv_dc_plane_ex(stream, c->plan[1], c->d_act[a - 1], c->packed[a], c->bias[a], c->act[a], nullptr, c->d_act[a],
-                                         3 * B, H, W, 3, c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+            if (dc(a, c->d_act[a - 1], nullptr, c->d_act[a], 3 * B, p)) return 1;
             prof_mark(c, c->ev_dc, c->n_dc, s);
             prof_mark(c, c->ev_dc, c->n_dc, s);
-            if (lic360_cconv_dc_plane_ex(stream, c->plan[1], c->d_act[a], c->packed[b2], c->bias[b2], c->act[b2], c->d_act[a - 1], c->d_act[b2],
-                                         3 * B, H, W, 3, c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+            if (dc(b2, c->d_act[a], c->d_act[a - 1], c->d_act[b2], 3 * B, p)) return 1;
             prof_mark(c, c->ev_dc, c->n_dc, s);
         }
-        if (lic360_cconv_dc_plane_ex(stream, c->plan[2], c->d_act[10], c->packed[11], c->bias[11], nullptr, nullptr, c->d_y, 3 * B, H, W, 3,
-                                     c->d_idx, c->d_pidx, pih, p, 3 * B, 1)) return 1;
+        if (dc(11, c->d_act[10], nullptr, c->d_y, 3 * B, p)) return 1;
         int start, len;
         lic360_plane_window(p, G, H, W, pih, &start, &len);
         hipLaunchKernelGGL(k_dec_plane, dim3(B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,

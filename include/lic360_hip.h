@@ -128,6 +128,17 @@ int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *plan, const f
                              const float *act, const float *residual, float *out, int n, int h, int w, int nb,
                              const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod, int skewed);
 
+/* Leaf-resident variant (v_mfma_f32_4x4x1, csrc/cconv4_kernels.hip) for the latent-net shapes cin in {1,4},
+ * cout <= 4, ngroup <= 64: same results bit for bit, own weight layout.  EC: NCHW.  DC: diagonal-major
+ * activations [n][c][th+tw][th], min(h,w) <= 64. */
+int lic360_conv4_supported(const lic360_conv_plan *plan);
+long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
+int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);
+int lic360_cconv4_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
+                     const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
+int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
+                           const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
+
 /* ---- A19/A20 arithmetic coder (host side, as in the reference) ----------------------------- */
 /* Coder operates on HOST int32 tables exactly like the reference's Coder (extension/coder.h:10-63,
  * extension/coder.cpp:30-113): the op API hands it CPU tensors. */

@@ -303,3 +303,37 @@ def test_context_layouts(lic):
     sk = host(lic.ContexShiftOp(False, 3, 0, False).forward(dev(x))[0])
     assert np.array_equal(sk, orc.contex_shift(x, 3, False))
     assert np.array_equal(host(lic.ContexShiftOp(True, 3, 0, False).forward(dev(sk))[0]), x)
+
+
+# ------------------------------------------------------------------ leaf-resident (4x4x1 MFMA) conv, direct C-ABI call
+@pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 7, 70), (6, 4, 4, True, True, 3, 3, 5, 66), (48, 4, 4, True, True, 3, 3, 3, 64),
+                                  (48, 4, 3, True, False, 3, 6, 4, 20), (48, 1, 4, False, True, 3, 3, 4, 130)],
+                         ids=lambda c: "g%d_%dto%d_%dx%d" % (c[0], c[1], c[2], c[7], c[8]))
+def test_cconv4_ec_bit_exact(lic, case):
+    import ctypes as C
+    G, cin, cout, hidden, act, nb, N, H, W = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    Cc, nout = G * cin, G * cout
+    w, b, a = conv_params(rng, nb, nout, Cc, act=act)
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
+    constrain = 6 if hidden else 5
+    ref = orc.cconv_ec(x, w, b, a, G, constrain) + res
+    L = lic._lib
+    plan = C.c_void_p(0)
+    assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
+    assert L.lic360_conv4_supported(plan) == 1
+    L.lic360_conv4_packed_floats.restype = C.c_long
+    L.lic360_conv4_packed_floats.argtypes = [C.c_void_p]
+    nper = L.lic360_conv4_packed_floats(plan)
+    packed = torch.empty(nb * nper, dtype=torch.float32, device="cuda:0")
+    xd, wd, bd, rd = dev(x), dev(w), dev(b), dev(res)
+    ad = dev(a) if act else None
+    out = torch.empty((N, nout, H, W), dtype=torch.float32, device="cuda:0")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    assert L.lic360_conv4_pack(s, plan, P(wd), nb, P(packed)) == 0
+    assert L.lic360_cconv4_ec(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, N) == 0, L.lic360_last_error()
+    got = host(out)
+    L.lic360_conv_plan_destroy(plan)
+    assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
