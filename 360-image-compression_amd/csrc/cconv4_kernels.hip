@@ -100,17 +100,65 @@ template <int CIN> struct NAcc { static constexpr int value = CIN == 4 ? 25 : 7;
 
 // one K step of lane class CLS: every active lane gets  acc = fma(w, x, acc).
 // DIAG: staged tile rows are anti-diagonals (row = kh+kw, col = kh + lane) instead of image rows (row = kh, col = kw + lane).
-template <int CIN, int CLS, int XPLANE, int COLS, bool DIAG>
+// A lane (tap kh,kw) is active in this step iff kh+kw < dlim.  While dlim >= 9 every lane is active and the step is one
+// straight-line block (all LDS reads can be hoisted above the 25 MFMAs); the last <= 8 steps of a chain run tap groups of
+// equal kh+kw under one scalar branch each.
+template <int CIN, int CLS, int I, int XPLANE, int COLS, bool DIAG>
+struct LaneOf {
+    static constexpr int tap = CIN == 4 ? I : CLS + 4 * I;
+    static constexpr bool valid = tap < 25;
+    static constexpr int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
+    static constexpr int xoff = gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw);
+};
+
+template <int CIN, int CLS, int XPLANE, int COLS, bool DIAG, bool FULL>
 __device__ __forceinline__ void conv4_step(f32x4 *acc, const float *xs, const f32x4 *ws4, int dlim, int lane, int xbase) {
+    constexpr int NA = NAcc<CIN>::value;
+    const f32x4 *wl = ws4 + CLS * 32 + (lane & 3);
+    const float *xl = xs + xbase;
+    if constexpr (FULL) {
+        // three register-bounded chunks (8 lanes each): reads of a chunk are issued together, then its MFMAs
+        constexpr int CH = 8;
 #pragma unroll
-    for (int i = 0; i < NAcc<CIN>::value; ++i) {
-        const int tap = CIN == 4 ? i : CLS + 4 * i;
-        if (tap < 25) {
-            const int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
-            if (kh + kw < dlim) {
-                const f32x4 a4 = ws4[(CLS * 8 + i / 4) * 4 + (lane & 3)];
-                const float bv = xs[xbase + gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
-                acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[i % 4], bv, acc[i], 4, 0, 0);
+        for (int c0 = 0; c0 < NA; c0 += CH) {
+            f32x4 a4[2];
+            float bv[CH];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a4[q] = wl[(c0 / 4 + q) * 4];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;       // compile-time after unrolling
+                const int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
+                bv[k] = (i < NA && tap < 25) ? xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
+                if (i < NA && tap < 25) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[k / 4][k % 4], bv[k], acc[i], 4, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+            if (d < dlim) {
+                f32x4 a4[(NA + 3) / 4];
+                float bv[NA];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int tap = CIN == 4 ? i : CLS + 4 * i;
+                    const int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
+                    if (tap < 25 && kh + kw == d) {
+                        a4[i / 4] = wl[(i / 4) * 4];
+                        bv[i] = xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int tap = CIN == 4 ? i : CLS + 4 * i;
+                    const int kh = tap / 5, kw = tap % 5;
+                    if (tap < 25 && kh + kw == d) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[i / 4][i % 4], bv[i], acc[i], 4, 0, 0);
+                }
             }
         }
     }
@@ -134,18 +182,23 @@ __device__ __forceinline__ f32x4 ec4_body(const float *__restrict__ xn, const f3
     for (int i = 0; i < NAcc<CIN>::value; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float xr[XLD];
     f32x4 wr = {0.f, 0.f, 0.f, 0.f};
-    auto gload = [&](int tc) {
+    // staging addresses are step-invariant up to + tc*CIN*H*W: resolve the index math once (-1 = outside the image)
+    int xo[XLD];
 #pragma unroll
-        for (int k = 0; k < XLD; ++k) {
-            int e = tid + k * C4_THREADS;
-            float v = 0.0f;
-            if (e < XS) {
-                int gid = e / XPLANE, q = e % XPLANE, rr = q / C4_COLS, cc = q % C4_COLS;
-                int gr = r0 - 2 + rr, gc = c0 - 2 + cc;
-                if (gr >= 0 && gr < H && gc >= 0 && gc < W) v = xn[((long)(tc * CIN + gid) * H + gr) * W + gc];
-            }
-            xr[k] = v;
+    for (int k = 0; k < XLD; ++k) {
+        int e = tid + k * C4_THREADS;
+        xo[k] = -1;
+        if (e < XS) {
+            int gid = e / XPLANE, q = e % XPLANE, rr = q / C4_COLS, cc = q % C4_COLS;
+            int gr = r0 - 2 + rr, gc = c0 - 2 + cc;
+            if (gr >= 0 && gr < H && gc >= 0 && gc < W) xo[k] = (gid * H + gr) * W + gc;
         }
+    }
+    const int tcs = CIN * H * W;
+    auto gload = [&](int tc) {
+        const float *xt = xn + (long)tc * tcs;
+#pragma unroll
+        for (int k = 0; k < XLD; ++k) xr[k] = xo[k] >= 0 ? xt[xo[k]] : 0.0f;
         if (tid < C4_WSLOTS) wr = wp[(long)tc * C4_WSLOTS + tid];
     };
     auto lstore = [&](int buf) {
@@ -160,10 +213,12 @@ __device__ __forceinline__ f32x4 ec4_body(const float *__restrict__ xn, const f3
     lstore(0);
     __syncthreads();
     const int xbase = ps * C4_COLS + lane;
+    // Lanes whose chain has ended (kh+kw >= g+4+hidden-tc) carry a zero weight in packed4, so every step is the same
+    // straight-line block of 25 MFMAs: fma(0, x, acc) == acc leaves their sums untouched.
     for (int tc = 0; tc < Lmax; ++tc) {
-        const int cur = tc & 1, dlim = g + 4 + hidden - tc;
+        const int cur = tc & 1;
         if (tc + 1 < Lmax) gload(tc + 1);
-        conv4_step<CIN, CLS, XPLANE, C4_COLS, false>(acc, xs[cur], ws4[cur], dlim, lane, xbase);
+        conv4_step<CIN, CLS, XPLANE, C4_COLS, false, true>(acc, xs[cur], ws4[cur], 9, lane, xbase);
         if (tc + 1 < Lmax) lstore(cur ^ 1);
         __syncthreads();
     }
@@ -249,25 +304,30 @@ __device__ __forceinline__ f32x4 dc4_body(const float *__restrict__ xn, const f3
     for (int i = 0; i < NAcc<CIN>::value; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float xr[XLD];
     f32x4 wr = {0.f, 0.f, 0.f, 0.f};
+    // staging addresses are step-invariant up to + tc*CIN*SK: resolve the index math once (-1 = outside the image)
+    int xo[XLD], xrow[XLD];
+#pragma unroll
+    for (int k = 0; k < XLD; ++k) {
+        int e = tid + k * C4_THREADS;
+        xo[k] = -1;
+        xrow[k] = 0;
+        if (e < XS) {
+            int gid = e / XPLANE, q = e % XPLANE, row = q / DC4_COLS, col = q % DC4_COLS;
+            int sp = s0 - (C4_PS - 1) - 4 + row, thp = th_base - 2 + col, twp = sp - thp;
+            xrow[k] = row;
+            if (sp >= 0 && sp < S && thp >= 0 && thp < H && twp >= 0 && twp < W) xo[k] = (int)(gid * SK + (long)sp * H + thp);
+        }
+    }
+    const f32x4 *wsrc = nullptr;
+    if (tid < C4_PS * C4_WSLOTS && g0 + (tid >> 7) < ngroup)
+        wsrc = packed4 + (((long)nbatch * ngroup + g0 + (tid >> 7)) * ngroup) * C4_WSLOTS + (tid & 127);
+    const long tcs = CIN * SK;
     auto gload = [&](int tc) {
         const int rlim = g0 + (C4_PS - 1) + 4 + hidden - tc;            // band rows >= rlim are not read in this step
+        const float *xt = xn + tc * tcs;
 #pragma unroll
-        for (int k = 0; k < XLD; ++k) {
-            int e = tid + k * C4_THREADS;
-            float v = 0.0f;
-            if (e < XS) {
-                int gid = e / XPLANE, q = e % XPLANE, row = q / DC4_COLS, col = q % DC4_COLS;
-                int sp = s0 - (C4_PS - 1) - 4 + row, thp = th_base - 2 + col, twp = sp - thp;
-                if (row < rlim && sp >= 0 && sp < S && thp >= 0 && thp < H && twp >= 0 && twp < W)
-                    v = xn[(long)(tc * CIN + gid) * SK + (long)sp * H + thp];
-            }
-            xr[k] = v;
-        }
-        if (tid < C4_PS * C4_WSLOTS) {
-            int gg = g0 + (tid >> 7);
-            wr = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (gg < ngroup) wr = packed4[(((long)nbatch * ngroup + gg) * ngroup + tc) * C4_WSLOTS + (tid & 127)];
-        }
+        for (int k = 0; k < XLD; ++k) xr[k] = (xo[k] >= 0 && xrow[k] < rlim) ? xt[xo[k]] : 0.0f;
+        if (wsrc) wr = wsrc[(long)tc * C4_WSLOTS];
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -283,9 +343,10 @@ __device__ __forceinline__ f32x4 dc4_body(const float *__restrict__ xn, const f3
     // tap (kh,kw) of the position `lane` on diagonal s: band row (s + kh+kw-4) - (s0-(PS-1)-4) = (PS-1-ps) + kh+kw, col (th_lo+lane+kh-2) - (th_base-2)
     const int xbase = (C4_PS - 1 - ps) * DC4_COLS + (glive ? th_lo - th_base : 0) + lane;
     for (int tc = 0; tc < Lwg; ++tc) {
-        const int cur = tc & 1, dlim = glive ? g + 4 + hidden - tc : 0;
+        const int cur = tc & 1;
         if (tc + 1 < Lwg) gload(tc + 1);
-        conv4_step<CIN, CLS, XPLANE, DC4_COLS, true>(acc, xs[cur], ws4[cur] + ps * C4_WSLOTS, dlim, lane, xbase);
+        if (glive && g + 4 + hidden - tc > 0)                           // this group's chains still run (zero weights past a lane's end)
+            conv4_step<CIN, CLS, XPLANE, DC4_COLS, true, true>(acc, xs[cur], ws4[cur] + ps * C4_WSLOTS, 9, lane, xbase);
         if (tc + 1 < Lwg) lstore(cur ^ 1);
         __syncthreads();
     }

@@ -1,0 +1,84 @@
+"""Per-image data parallelism over the GPUs of one node: ERP images are independent, so image i
+goes to rank i mod world, every rank owns one GPU and one codec, and NO data-path collective is needed.  The only
+cross-rank operations are the barrier + MAX of the wall time used for throughput reporting and an optional gather
+of per-image results (bitstream sizes / digests) to rank 0.  Works with backend "nccl" (= RCCL on ROCm) on GPUs and
+"gloo" on CPU (tests)."""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items, rank, world):
+    """Images handled by `rank`: i = rank, rank+world, ... (round-robin keeps shards within one image of each other)."""
+    return list(range(rank, n_items, world))
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run; returns (rank, local_rank, world)."""
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, local, world
+
+
+def fence(device=None):
+    """barrier + device synchronize on both sides of a timed region."""
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+
+def timed(fn, steps, device=None):
+    """Run fn() `steps` times between fences; returns the MAX wall time over ranks (seconds)."""
+    fence(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence(device)
+    dt = time.perf_counter() - t0
+    return reduce_max(dt, device)
+
+
+def reduce_max(value, device=None):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_ok(flag, device=None):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def gather_results(local_results, n_items):
+    """local_results: {image index: picklable}.  Returns the full list on rank 0 (None elsewhere)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [local_results[i] for i in range(n_items)]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local_results)
+    if dist.get_rank() != 0:
+        return None
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return [merged[i] for i in range(n_items)]

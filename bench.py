@@ -68,73 +68,78 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE.json configs[3]: 8 per GPU)")
+    ap.add_argument("--streams", type=int, default=2, help="the per-GPU batch is split over this many HIP streams so that one "
+                    "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
+    import lic360_shard as shard
+    import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
+    rank, local, world = shard.init_from_env("nccl")          # one process per GPU; "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local)
 
     import ref_codec as rc
     from lic360_fused import FusedCodec
     layers = rc.make_main_params(1000 * SSIM + MODEL_IDX, G)
     B = args.batch
-    codec = FusedCodec(G, H, W, max_batch=B, device=local)
-    codec.load_layers(layers)
+    ns = max(1, min(args.streams, B))
+    sizes = [B // ns + (1 if i < B % ns else 0) for i in range(ns)]
     code_np, mask_np = synth_latents(B, seed0=1000 * rank)
-    code, mask = torch.from_numpy(code_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    codecs, codes, masks, streams = [], [], [], []
+    o = 0
+    for sz in sizes:
+        c = FusedCodec(G, H, W, max_batch=sz, device=local)
+        c.load_layers(layers)
+        codecs.append(c)
+        codes.append(torch.from_numpy(code_np[o:o + sz]).to(dev))
+        masks.append(torch.from_numpy(mask_np[o:o + sz]).to(dev))
+        streams.append(torch.cuda.Stream(device=dev))
+        o += sz
+    torch.cuda.synchronize(dev)
 
     def step():
-        codec.encode_async(code, mask)
-        codec.decode_async(mask, B)
+        for c, cd, mk, st in zip(codecs, codes, masks, streams):
+            with torch.cuda.stream(st):
+                c.encode_async(cd, mk)
+        for c, cd, mk, st in zip(codecs, codes, masks, streams):
+            with torch.cuda.stream(st):
+                c.decode_async(mk, cd.shape[0])
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    def roundtrip_ok():
+        return all(bool(torch.equal(c.code_out[:cd.shape[0]], cd * mk)) and int(c.err[:cd.shape[0]].abs().sum().item()) == 0
+                   for c, cd, mk in zip(codecs, codes, masks))
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
     # correctness of what is being timed: decode(encode(x)) == x on every rank, no coder faults
-    ok = bool(torch.equal(codec.code_out[:B], code * mask)) and int(codec.err[:B].abs().sum().item()) == 0
-    codec.profile(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = codec.profile_read()
-    codec.profile(False)
-    ok = ok and bool(torch.equal(codec.code_out[:B], code * mask))
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        okt = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
+    ok = roundtrip_ok()
+    for c in codecs:
+        c.profile(True)
+    dt = shard.timed(step, args.steps, dev)                   # barrier + sync both sides, MAX over ranks
+    prof = {"ec_ms": 0.0, "ec_launches": 0, "dc_ms": 0.0, "dc_launches": 0}
+    for c in codecs:
+        pr = c.profile_read()
+        for k in prof:
+            prof[k] += pr[k]
+        c.profile(False)
+    ok = ok and roundtrip_ok()
+    ok = shard.all_ok(ok, dev)
 
     if rank == 0:
         images = world * B * args.steps
         value = images * PIXELS / dt / 1e6
-        nbytes = codec.nbytes[:B].cpu().numpy()
+        nbytes = np.concatenate([c.nbytes[:cd.shape[0]].cpu().numpy() for c, cd in zip(codecs, codes)])
         # dominant kernel: hidden-layer masked conv, encode order vs decode order
         ec_t, dc_t = prof["ec_ms"], prof["dc_ms"]
         if dc_t >= ec_t:
             name, tot_ms, launches = "k_cconv_dc (decode order, hidden layer)", dc_t, prof["dc_launches"]
-            flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)
+            flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)   # all hidden DC launches of a step cover B images x 10 layers
         else:
             name, tot_ms, launches = "k_cconv_ec (encode order, hidden layer)", ec_t, prof["ec_launches"]
-            flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B
+            flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)
         avg_ms = tot_ms / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
@@ -144,7 +149,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic 512x1024 ERP latents per GPU (48x64x128 symbols + importance mask), "
                                    "model-idx 3 --ssim seeded weights, latent entropy encode+decode (BASELINE.json configs[3] per-GPU share)" % B,
-                       "images_per_gpu_per_step": B, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean())},
+                       "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean())},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": launches,

@@ -1,19 +1,25 @@
-"""Body of __graft_entry__.smoke(): cconv_ec + gmm table on a tiny latent vs the oracle (bit-exact)."""
+"""Body of __graft_entry__.smoke(): one small encode -> decode of a synthetic latent batch through the
+device-resident HIP codec on cuda:0; bitstreams and symbols are checked against the CPU oracle pipeline."""
 import numpy as np
 import torch
 
-import oracle as orc
-from util import conv_params
+import ref_codec as rc
+from util import latent
 
 
 def run():
-    import lic360
+    from lic360_fused import FusedCodec
+    G, H, W, B = 8, 8, 16, 2
     rng = np.random.default_rng(0)
-    G, H, W = 6, 8, 16
-    w, b, a = conv_params(rng, 3, G * 4, G * 4)
-    x = rng.standard_normal((3, G * 4, H, W)).astype(np.float32)
-    ref = orc.cconv_ec(x, w, b, a, G, 6)
-    op = lic360.CconvEcOp(G * 4, G, G * 4, 5, 6, 0, False)
-    d = lambda t: torch.from_numpy(t).to("cuda:0")
-    got = op.forward_act_batch(d(x), d(w), d(b), d(a))[0].cpu().numpy()
-    assert np.array_equal(got, ref), "cconv_ec mismatch vs oracle"
+    layers = rc.make_main_params(1003, G)
+    items = [latent(rng, G, H, W) for _ in range(B)]
+    code = np.concatenate([it[0] for it in items], 0)
+    mask = np.concatenate([it[1] for it in items], 0)
+    fc = FusedCodec(G, H, W, max_batch=B)
+    fc.load_layers(layers)
+    d = lambda a: torch.from_numpy(a).to("cuda:0")
+    streams = fc.encode(d(code), d(mask))
+    for i in range(B):
+        assert streams[i] == rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G), "bitstream %d differs from the oracle" % i
+    out = fc.decode(streams, d(mask)).cpu().numpy()
+    assert np.array_equal(out, code * mask), "decoded symbols differ"
