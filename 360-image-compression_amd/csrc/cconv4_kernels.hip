@@ -22,10 +22,10 @@
 //
 // Encode order (EC4): workgroup = 12 waves = 3 consecutive rows x 64 columns of one (sample, group); the
 // 7 x 68 halo tile of the step's cin channels and the step's 2 KB of weights are double-buffered in LDS.
-// Decode order (DC4): workgroup = 12 waves = 3 adjacent groups (adjacent anti-diagonals of the current
-// plane) of one sample; lanes run along the diagonal in a diagonal-major activation layout
-// [n][c][th+tw][th], so the 11 x 71 halo band (shared by the 3 diagonals) loads and the output stores are
-// contiguous.
+// Decode order (DC4, cconv4v3_dc.inc): persistent workgroups of 12 waves = 3 adjacent groups (adjacent
+// anti-diagonals of the current plane) of one sample; lanes run along the diagonal in a zero-padded diagonal-major
+// activation layout, so the 11 x 72 halo band shared by the 3 diagonals is fetched with unconditional 16-byte
+// LDS-DMA loads and the output stores are contiguous.
 #include "common.h"
 #include "conv_plan.h"
 
@@ -285,136 +285,18 @@ LIC360_API int lic360_cconv4_ec(void *stream, const lic360_conv_plan *p, const f
 }
 
 // ------------------------------------------------------------------------------------------------ DC4
-// Activations in diagonal-major layout [n][c][s = th+tw][th] (S = H+W-1 diagonals of H slots).
-// Workgroup = groups g0..g0+PS-1 (anti-diagonals s0, s0-1, .. with s0 = psum - g0) of one sample.
-// Staged band: band[gid][row][col] = x[ch][(th, tw)] with th + tw = s0 - (PS-1) - 4 + row, th = th_base - 2 + col,
-// th_base = first row index of the lowest diagonal (s0 - (PS-1)).
-#define DC4_ROWS (9 + C4_PS - 1)
-#define DC4_COLS (68 + C4_PS - 1 + 1)
-template <int CIN, int CLS>
-__device__ __forceinline__ f32x4 dc4_body(const float *__restrict__ xn, const f32x4 *__restrict__ packed4, float (*xs)[CIN * DC4_ROWS * DC4_COLS],
-                                          f32x4 (*ws4)[C4_PS * C4_WSLOTS], int tid, int lane, int ps, int g0, int g, bool glive, int hidden,
-                                          int Lwg, int s0, int th_base, int th_lo, int nbatch, int ngroup, int H, int W) {
-    constexpr int XPLANE = DC4_ROWS * DC4_COLS, XS = CIN * XPLANE;
-    constexpr int XLD = (XS + C4_THREADS - 1) / C4_THREADS;
-    const int S = H + W - 1;
-    const long SK = (long)S * H;
-    f32x4 acc[NAcc<CIN>::value];
-#pragma unroll
-    for (int i = 0; i < NAcc<CIN>::value; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float xr[XLD];
-    f32x4 wr = {0.f, 0.f, 0.f, 0.f};
-    // staging addresses are step-invariant up to + tc*CIN*SK: resolve the index math once (-1 = outside the image)
-    int xo[XLD], xrow[XLD];
-#pragma unroll
-    for (int k = 0; k < XLD; ++k) {
-        int e = tid + k * C4_THREADS;
-        xo[k] = -1;
-        xrow[k] = 0;
-        if (e < XS) {
-            int gid = e / XPLANE, q = e % XPLANE, row = q / DC4_COLS, col = q % DC4_COLS;
-            int sp = s0 - (C4_PS - 1) - 4 + row, thp = th_base - 2 + col, twp = sp - thp;
-            xrow[k] = row;
-            if (sp >= 0 && sp < S && thp >= 0 && thp < H && twp >= 0 && twp < W) xo[k] = (int)(gid * SK + (long)sp * H + thp);
-        }
-    }
-    const f32x4 *wsrc = nullptr;
-    if (tid < C4_PS * C4_WSLOTS && g0 + (tid >> 7) < ngroup)
-        wsrc = packed4 + (((long)nbatch * ngroup + g0 + (tid >> 7)) * ngroup) * C4_WSLOTS + (tid & 127);
-    const long tcs = CIN * SK;
-    auto gload = [&](int tc) {
-        const int rlim = g0 + (C4_PS - 1) + 4 + hidden - tc;            // band rows >= rlim are not read in this step
-        const float *xt = xn + tc * tcs;
-#pragma unroll
-        for (int k = 0; k < XLD; ++k) xr[k] = (xo[k] >= 0 && xrow[k] < rlim) ? xt[xo[k]] : 0.0f;
-        if (wsrc) wr = wsrc[(long)tc * C4_WSLOTS];
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < XLD; ++k) {
-            int e = tid + k * C4_THREADS;
-            if (e < XS) xs[buf][e] = xr[k];
-        }
-        if (tid < C4_PS * C4_WSLOTS) ws4[buf][tid] = wr;
-    };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    // tap (kh,kw) of the position `lane` on diagonal s: band row (s + kh+kw-4) - (s0-(PS-1)-4) = (PS-1-ps) + kh+kw, col (th_lo+lane+kh-2) - (th_base-2)
-    const int xbase = (C4_PS - 1 - ps) * DC4_COLS + (glive ? th_lo - th_base : 0) + lane;
-    for (int tc = 0; tc < Lwg; ++tc) {
-        const int cur = tc & 1;
-        if (tc + 1 < Lwg) gload(tc + 1);
-        if (glive && g + 4 + hidden - tc > 0)                           // this group's chains still run (zero weights past a lane's end)
-            conv4_step<CIN, CLS, XPLANE, DC4_COLS, true, true>(acc, xs[cur], ws4[cur] + ps * C4_WSLOTS, 9, lane, xbase);
-        if (tc + 1 < Lwg) lstore(cur ^ 1);
-        __syncthreads();
-    }
-    return Tree4<CIN, CLS, 4>::eval(acc);
-}
-
-template <int CIN>
-__global__ __launch_bounds__(C4_THREADS) void k_cconv4_dc(
-    const float *__restrict__ x, const float *__restrict__ packed, const float *__restrict__ bias, const float *__restrict__ act,
-    const float *__restrict__ residual, float *__restrict__ out, int ngroup, int cout, int hidden, int H, int W, int npb, int x_mod,
-    int psum) {
-    constexpr int XS = CIN * DC4_ROWS * DC4_COLS;
-    __shared__ float xs[2][XS];
-    __shared__ f32x4 ws4[2][C4_PS * C4_WSLOTS];
-    __shared__ float comb[C4_COMB_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), ps = wave >> 2, cls = wave & 3;
-    const int g0 = blockIdx.x * C4_PS, n = blockIdx.y, nbatch = n / npb;
-    const int S = H + W - 1;
-    const int s0 = psum - g0;                                           // diagonal of group g0; group g0+k sits on s0-k
-    if (s0 - (C4_PS - 1) >= S || s0 < 0) return;                        // no group of this block is on the plane
-    const int g = g0 + ps, s = s0 - ps;
-    const bool glive = g < ngroup && s >= 0 && s < S;
-    const int sb = s0 - (C4_PS - 1) > 0 ? s0 - (C4_PS - 1) : 0;
-    const int th_base = sb >= W ? sb - W + 1 : 0;
-    const int th_lo = glive ? (s >= W ? s - W + 1 : 0) : 0, th_hi = glive ? (s < H ? s : H - 1) : -1;
-    const int C = ngroup * CIN, nout = ngroup * cout;
-    int Lwg = g0 + (C4_PS - 1) + 4 + hidden;                            // longest chain in the block
-    if (Lwg > ngroup) Lwg = ngroup;
-    const long SK = (long)S * H;
-    const float *xn = x + (long)(n % x_mod) * C * SK;
-    const f32x4 *p4 = (const f32x4 *)packed;
-    f32x4 part;
-    switch (cls) {
-        case 0: part = dc4_body<CIN, 0>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
-        case 1: part = dc4_body<CIN, 1>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
-        case 2: part = dc4_body<CIN, 2>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
-        default: part = dc4_body<CIN, 3>(xn, p4, xs, ws4, tid, lane, ps, g0, g, glive, hidden, Lwg, s0, th_base, th_lo, nbatch, ngroup, H, W); break;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) comb[((ps * 4 + cls) * 4 + r) * 64 + lane] = part[r];
-    __syncthreads();
-    const int r = cls, th = th_lo + lane;
-    if (glive && r < cout && th <= th_hi) {
-        const float f0 = comb[((ps * 4 + 0) * 4 + r) * 64 + lane], f1 = comb[((ps * 4 + 1) * 4 + r) * 64 + lane];
-        const float f2 = comb[((ps * 4 + 2) * 4 + r) * 64 + lane], f3 = comb[((ps * 4 + 3) * 4 + r) * 64 + lane];
-        const int o = g * cout + r, bid = nbatch * nout + o;
-        float sv = ((f0 + f2) + (f1 + f3)) + bias[bid];
-        if (act) { if (sv < 0) sv = sv * act[bid]; }                    // cconv_dc_cuda.cu:360-362
-        const long oi = ((long)n * nout + o) * SK + (long)s * H + th;
-        if (residual) sv = sv + residual[oi];                           // fused TileAdd
-        out[oi] = sv;
-    }
-}
+#include "cconv4v3_dc.inc"
 
 LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
     ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
     ARG_CHECK(h <= 64 || w <= 64);                                      // an anti-diagonal must fit one wave (64 positions)
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
-    const int hidden = p->constrain == 5 ? 0 : 1;
-    dim3 grid((p->ngroup + C4_PS - 1) / C4_PS, n, 1);
-    if (p->cin == 4)
-        hipLaunchKernelGGL(k_cconv4_dc<4>, grid, dim3(C4_THREADS), 0, (hipStream_t)stream, x, packed4, bias, act, residual, out, p->ngroup,
-                           p->cout, hidden, h, w, n / nb, x_mod, psum);
-    else
-        hipLaunchKernelGGL(k_cconv4_dc<1>, grid, dim3(C4_THREADS), 0, (hipStream_t)stream, x, packed4, bias, act, residual, out, p->ngroup,
-                           p->cout, hidden, h, w, n / nb, x_mod, psum);
-    LAUNCH_CHECK();
+    return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
+}
+
+LIC360_API int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0) {
+    ARG_CHECK(rows && pitch && row0 && col0 && h > 0 && w > 0);
+    *rows = D3_SP(h, w); *pitch = D3_HP(h); *row0 = D3_S0; *col0 = D3_C0;
     return 0;
 }

@@ -26,6 +26,7 @@ struct AcDevState {            // per-image decoder state carried across planes
 
 struct lic360_codec {
     int G, H, W, maxB, S, P, HW;
+    int sk_rows, sk_pitch, sk_row0, sk_col0;   // diagonal-major decode layout: cell (s, th) at [(s + row0) * pitch + th + col0]
     lic360_conv_plan *plan[3];                 // first, hidden, last
     float *packed[12], *bias[12], *act[12];
     float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
@@ -156,9 +157,11 @@ __global__ void k_dec_init(const uint8_t *__restrict__ bytes, long cap, const in
 __global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, const float *__restrict__ mask, const int *__restrict__ idx,
                                                   int start, int len, int p, AcDevState *__restrict__ state,
                                                   const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes,
-                                                  float *__restrict__ x0, float *__restrict__ code_out, int B, int G, int H, int W) {
+                                                  float *__restrict__ x0, float *__restrict__ code_out, int B, int G, int H, int W,
+                                                  int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int HW = H * W, S = H + W - 1;
+    const int HW = H * W;
+    const long SK = (long)sk_rows * sk_pitch;
     AcDevState ds = state[b];
     AcState st;
     st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = ds.error;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, c
             for (int net = 0; net < 3; ++net)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    v[net * 3 + c] = y[(((long)(net * B + b) * (3 * G) + g * 3 + c) * S + (th + tw)) * H + th];
+                    v[net * 3 + c] = y[((long)(net * B + b) * (3 * G) + g * 3 + c) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0];
             gmm_cdf9(v, v + 3, v + 6, T);
         }
         const unsigned long long cmask = __ballot(coded);
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, c
             symv = (lane == j) ? sym : symv;
         }
         if (live) {
-            x0[(((long)b * G + g) * S + (th + tw)) * H + th] = coded ? (float)symv - 3.5f : 0.0f;
+            x0[((long)b * G + g) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0] = coded ? (float)symv - 3.5f : 0.0f;
             code_out[nchw] = coded ? (float)symv : 0.0f;
         }
     }
@@ -259,19 +262,21 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     HIP_TRY(hipMemcpy(c->d_idx, c->h_idx.data(), c->h_idx.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_pidx, c->h_pidx.data(), c->h_pidx.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_plane_start, c->h_plane_start.data(), c->h_plane_start.size() * 4, hipMemcpyHostToDevice));
-    const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->S * h;
+    if (c->use4) { if (lic360_dc4_layout(h, w, &c->sk_rows, &c->sk_pitch, &c->sk_row0, &c->sk_col0)) return 1; }
+    else { c->sk_rows = c->S; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
+    const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = 4096;   // TAIL: band fetches may run past the last row
     rc |= dmalloc(&c->e_x0, B * G * HW);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], 3 * B * 4 * G * HW);
     rc |= dmalloc(&c->e_rec, B * G * HW);
-    rc |= dmalloc(&c->d_x0, B * G * SK);
-    for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], 3 * B * 4 * G * SK);
-    rc |= dmalloc(&c->d_y, 3 * B * 3 * G * SK);
+    rc |= dmalloc(&c->d_x0, B * G * SK + TAIL);
+    for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], 3 * B * 4 * G * SK + TAIL);
+    rc |= dmalloc(&c->d_y, 3 * B * 3 * G * SK + TAIL);
     rc |= dmalloc(&c->d_state, B);
     if (rc) return 1;
     // decode activations are only ever read where already written or with a zero weight; they must be finite
-    HIP_TRY(hipMemset(c->d_x0, 0, B * G * SK * 4));
-    for (int i = 0; i < 11; ++i) HIP_TRY(hipMemset(c->d_act[i], 0, 3 * B * 4 * G * SK * 4));
-    HIP_TRY(hipMemset(c->d_y, 0, 3 * B * 3 * G * SK * 4));
+    HIP_TRY(hipMemset(c->d_x0, 0, (B * G * SK + TAIL) * 4));
+    for (int i = 0; i < 11; ++i) HIP_TRY(hipMemset(c->d_act[i], 0, (3 * B * 4 * G * SK + TAIL) * 4));
+    HIP_TRY(hipMemset(c->d_y, 0, (3 * B * 3 * G * SK + TAIL) * 4));
     *out = c;
     return 0;
 }
@@ -379,7 +384,7 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
         int start, len;
         lic360_plane_window(p, G, H, W, pih, &start, &len);
         hipLaunchKernelGGL(k_dec_plane, dim3(B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
-                           c->d_x0, code_out, B, G, H, W);
+                           c->d_x0, code_out, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);

@@ -129,8 +129,10 @@ int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *plan, const f
                              const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod, int skewed);
 
 /* Leaf-resident variant (v_mfma_f32_4x4x1, csrc/cconv4_kernels.hip) for the latent-net shapes cin in {1,4},
- * cout <= 4, ngroup <= 64: same results bit for bit, own weight layout.  EC: NCHW.  DC: diagonal-major
- * activations [n][c][th+tw][th], min(h,w) <= 64. */
+ * cout <= 4, ngroup <= 64: same results bit for bit, own weight layout.  EC: NCHW.  DC: zero-padded diagonal-major
+ * activations [n][c][rows][pitch] with cell (s = th+tw, th) at [(s + row0) * pitch + th + col0] (lic360_dc4_layout; the
+ * padding must be zero and the buffer must extend 16 KB past the last row), min(h,w) <= 64. */
+int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0);
 int lic360_conv4_supported(const lic360_conv_plan *plan);
 long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);
