@@ -286,6 +286,7 @@ LIC360_API int lic360_cconv4_ec(void *stream, const lic360_conv_plan *p, const f
 
 // ------------------------------------------------------------------------------------------------ DC4
 #include "cconv4v3_dc.inc"
+#include "cconv4v3_ec.inc"
 
 LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
@@ -299,4 +300,16 @@ LIC360_API int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0,
     ARG_CHECK(rows && pitch && row0 && col0 && h > 0 && w > 0);
     *rows = D3_SP(h, w); *pitch = D3_HP(h); *row0 = D3_S0; *col0 = D3_C0;
     return 0;
+}
+
+// encode order on zero-padded activations [n][c][E3_HP(h)][E3_WP(w)] (cell (r, c) at [(r+2)*WP + c+2]); used by the fused codec
+LIC360_API int lic360_ec4_layout(int h, int w, int *hp, int *wp) {
+    ARG_CHECK(hp && wp && h > 0 && w > 0);
+    *hp = E3_HP(h); *wp = E3_WP(w);
+    return 0;
+}
+LIC360_API int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod) {
+    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
+    return launch_cconv4v3_ec((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, x_mod);
 }

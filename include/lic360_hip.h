@@ -133,6 +133,11 @@ int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *plan, const f
  * activations [n][c][rows][pitch] with cell (s = th+tw, th) at [(s + row0) * pitch + th + col0] (lic360_dc4_layout; the
  * padding must be zero and the buffer must extend 16 KB past the last row), min(h,w) <= 64. */
 int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0);
+/* encode order on zero-padded NCHW planes [hp][wp] with cell (r, c) at [(r+2)*wp + c+2] (lic360_ec4_layout): unconditional
+ * 16-byte LDS-DMA tile fetches, persistent workgroups; the padding must be zero, buffers extend 16 KB past the end */
+int lic360_ec4_layout(int h, int w, int *hp, int *wp);
+int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
+                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
 int lic360_conv4_supported(const lic360_conv_plan *plan);
 long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);
