@@ -149,6 +149,22 @@ AC_HD uint32_t ac_decode_target(const AcState &s, uint32_t total) {
     if (total == 65536u) return ac_div48(((offset + 1) << 16) - 1, range);
     return (uint32_t)(((offset + 1) * total - 1) / range);
 }
+// R: any bit source with  uint32_t get(int n)  returning the next n (<= 32) bits MSB-first, zeros past the end
+struct AcHostBits {
+    AcBitReader &r;
+    AC_HD uint32_t get(int n) { return ac_br_get(r, n); }
+};
+template <class R>
+AC_HD void ac_decode_consume_from(AcState &s, R &bits, uint32_t symLow, uint32_t symHigh, uint32_t total) {
+    int n1, n2;
+    uint32_t lowb;
+    ac_narrow(s, symLow, symHigh, total, n1, n2, lowb);
+    uint32_t code = s.code;
+    if (n1) code = (n1 == 32 ? 0u : (code << n1)) | bits.get(n1);
+    if (n2) code = (code & 0x80000000u) | ((code << n2) & 0x7fffffffu) | bits.get(n2);
+    s.code = code;
+    if (code < s.low || code > s.high) s.error = 3;
+}
 AC_HD void ac_decode_consume(AcState &s, AcBitReader &r, uint32_t symLow, uint32_t symHigh, uint32_t total) {
     int n1, n2;
     uint32_t lowb;

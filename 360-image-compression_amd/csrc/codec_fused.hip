@@ -150,12 +150,48 @@ __global__ void k_dec_init(const uint8_t *__restrict__ bytes, long cap, const in
     ac_br_init(rd, bytes + (long)b * cap, nbytes[b]);
     AcState st;
     ac_init(st);
-    ac_decode_start(st, rd);
+    ac_decode_start(st, rd);                                          // consumes exactly 4 bytes: pos = 4, no pending bits
     AcDevState d;
     d.low = st.low; d.high = st.high; d.code = st.code; d.error = 0; d.pad = 0;
-    d.pos = rd.pos; d.acc = rd.acc; d.nacc = rd.nacc;
+    d.pos = rd.pos; d.acc = 0; d.nacc = 0;
     state[b] = d;
 }
+
+// Wave-resident bit source for the decoder: lane i of `win` holds stream bytes [wbase+4i, wbase+4i+4) as a big-endian
+// word (zeros past the end), so a 32-bit refill is one v_readlane instead of dependent byte loads from global memory;
+// the 256-byte window is re-fetched with one coalesced load when the read position leaves it.
+struct DevBits {
+    const uint8_t *buf;
+    long len, pos;              // pos: next unread byte (multiple of 4)
+    unsigned long long acc;
+    int nacc;
+    long wbase;
+    uint32_t win;
+    int lane;
+    __device__ __forceinline__ void fetch_window() {
+        wbase = pos;
+        const long o = wbase + 4 * lane;
+        uint32_t w = 0;
+        if (o < len) {
+            w = *(const uint32_t *)(buf + o);                           // streams start 4-byte aligned (cap % 4 == 0)
+            w = __builtin_bswap32(w);
+            if (o + 4 > len) w &= 0xffffffffu << (8 * (int)(o + 4 - len));
+        }
+        win = w;
+    }
+    __device__ __forceinline__ uint32_t get(int n) {
+        if (nacc < n) {
+            if (pos >= wbase + 256) fetch_window();
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)((pos - wbase) >> 2));
+            acc = (acc << 32) | w;
+            nacc += 32;
+            pos += 4;
+        }
+        nacc -= n;
+        const unsigned long long v = acc >> nacc;
+        return (uint32_t)(n == 32 ? v : (v & ((1ull << n) - 1ull)));
+    }
+};
 
 // One wave per image and plane: tables for 64 plane positions in parallel, serial range decode on the
 // wave-uniform state, then scatter of (sym-3.5 | 0) into the diagonal-major input of the next plane and
@@ -171,8 +207,9 @@ __global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, c
     AcDevState ds = state[b];
     AcState st;
     st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = ds.error;
-    AcBitReader rd;
-    rd.buf = bytes + (long)b * cap; rd.len = nbytes[b]; rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc;
+    DevBits rd;
+    rd.buf = bytes + (long)b * cap; rd.len = nbytes[b]; rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
+    rd.fetch_window();
     for (int base = 0; base < len; base += 64) {
         const int cnt = (len - base) < 64 ? (len - base) : 64;
         const bool live = lane < cnt;
@@ -207,7 +244,7 @@ __global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, c
             uint32_t lo = 0, hi = 65536;
 #pragma unroll
             for (int k = 0; k < 8; ++k) if (sym == k) { lo = (uint32_t)t[k]; hi = (uint32_t)t[k + 1]; }
-            ac_decode_consume(st, rd, lo, hi, 65536u);
+            ac_decode_consume_from(st, rd, lo, hi, 65536u);
             symv = (lane == j) ? sym : symv;
         }
         if (live) {
@@ -367,7 +404,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
 LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
                                    const float *mask, int B, float *code_out, int *err) {
     if (check_ready(c, B)) return 2;
-    ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0);
+    ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0 && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
     const int G = c->G, H = c->H, W = c->W;
     hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);

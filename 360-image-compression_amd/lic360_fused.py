@@ -21,6 +21,7 @@ class FusedCodec(object):
         # worst case of this coder is < 2.1 bytes/symbol (16-bit CDF, frequency >= 1); 1 byte/symbol is ample for
         # any real table and overflow is reported through err[] rather than written out of bounds
         self.cap = int(cap_bytes) if cap_bytes else max(4096, self.G * self.H * self.W)
+        self.cap = (self.cap + 3) // 4 * 4              # streams start word-aligned (the device bit reader fetches words)
         self._h = C.c_void_p(0)
         with torch.cuda.device(self.device):
             _chk(_lib.lic360_codec_create(self.G, self.H, self.W, self.maxB, C.byref(self._h)))

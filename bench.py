@@ -24,6 +24,9 @@ for p in (os.path.join(ROOT, "360-image-compression_amd"), os.path.join(ROOT, "o
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# the oracle's OpenMP pool: the GPU box gives one GPU a 16-core CPU share
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -46,10 +49,10 @@ def synth_latents(batch, seed0):
 
 
 def cpu_baseline(layers):
-    """Oracle enc+dec of a 16x32 crop of one latent (1/16 of an image: full 48-group, 12-layer, 3-net model)."""
+    """Oracle enc+dec of a 32x32 crop of one latent (1/8 of an image: full 48-group, 12-layer, 3-net model)."""
     import ref_codec as rc
     from util import latent
-    ch, cw = 16, 32
+    ch, cw = 32, 32
     code, mask, _ = latent(np.random.default_rng(99), G, ch, cw)
     t0 = time.time()
     data = rc.encode_main(code, mask, layers, G)
@@ -57,7 +60,7 @@ def cpu_baseline(layers):
     dt = time.time() - t0
     assert np.array_equal(out, code * mask)
     px = PIXELS * (ch * cw) / float(H * W)
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = int(os.environ["OMP_NUM_THREADS"])
     return {"value": px / dt / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
             "sample": "oracle enc+dec of one %dx%d latent crop (=%d px of a 512x1024 ERP), full 12-layer x3 model, %.1f s" % (ch, cw, int(px), dt)}
 
@@ -67,9 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE.json configs[3] shards a 64-image batch; "
-                    "64 resident images per GPU keep the decode wavefront wide enough to fill 256 CUs)")
-    ap.add_argument("--streams", type=int, default=2, help="the per-GPU batch is split over this many HIP streams so that one "
+    ap.add_argument("--batch", type=int, default=96, help="images per GPU per step (BASELINE.json configs[3] shards a 64-image batch; "
+                    "96 resident images per GPU (3 sub-batches of 32) keep the decode wavefront wide enough to fill 256 CUs)")
+    ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
                     "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -136,10 +139,10 @@ def main():
         # dominant kernel: hidden-layer masked conv, encode order vs decode order
         ec_t, dc_t = prof["ec_ms"], prof["dc_ms"]
         if dc_t >= ec_t:
-            name, tot_ms, launches = "k_cconv_dc (decode order, hidden layer)", dc_t, prof["dc_launches"]
+            name, tot_ms, launches = "k_cconv4v3_dc<4> (decode order, hidden layers)", dc_t, prof["dc_launches"]
             flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)   # all hidden DC launches of a step cover B images x 10 layers
         else:
-            name, tot_ms, launches = "k_cconv_ec (encode order, hidden layer)", ec_t, prof["ec_launches"]
+            name, tot_ms, launches = "k_cconv4v3_ec<4> (encode order, hidden layers)", ec_t, prof["ec_launches"]
             flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)
         avg_ms = tot_ms / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
