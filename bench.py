@@ -49,10 +49,10 @@ def synth_latents(batch, seed0):
 
 
 def cpu_baseline(layers):
-    """Oracle enc+dec of a 32x32 crop of one latent (1/8 of an image: full 48-group, 12-layer, 3-net model)."""
+    """Oracle enc+dec of a 64x64 crop of one latent (half an image: full 48-group, 12-layer, 3-net model)."""
     import ref_codec as rc
     from util import latent
-    ch, cw = 32, 32
+    ch, cw = 64, 64
     code, mask, _ = latent(np.random.default_rng(99), G, ch, cw)
     t0 = time.time()
     data = rc.encode_main(code, mask, layers, G)
@@ -130,6 +130,15 @@ def main():
             prof[k] += pr[k]
         c.profile(False)
     ok = ok and roundtrip_ok()
+    # the same kernels with the GPU to themselves: one sub-batch, one stream (per-launch durations above are stretched by
+    # the other streams' kernels sharing the CUs)
+    codecs[0].profile(True)
+    with torch.cuda.stream(streams[0]):
+        codecs[0].encode_async(codes[0], masks[0])
+        codecs[0].decode_async(masks[0], codes[0].shape[0])
+    torch.cuda.synchronize(dev)
+    iso = codecs[0].profile_read()
+    codecs[0].profile(False)
     ok = shard.all_ok(ok, dev)
 
     if rank == 0:
@@ -145,6 +154,10 @@ def main():
             name, tot_ms, launches = "k_cconv4v3_ec<4> (encode order, hidden layers)", ec_t, prof["ec_launches"]
             flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)
         avg_ms = tot_ms / max(launches, 1)
+        b0 = int(codes[0].shape[0])
+        iso_ms = (iso["dc_ms"] / max(iso["dc_launches"], 1)) if dc_t >= ec_t else (iso["ec_ms"] / max(iso["ec_launches"], 1))
+        iso_flops = 2 * HIDDEN_GMAC * 1e9 * b0 * 10 / max(iso["dc_launches"] if dc_t >= ec_t else iso["ec_launches"], 1)
+        iso_tf = iso_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "ERP Mpixels/s enc+dec @512x1024 model-idx 3; bitstream bit-exact vs ref",
@@ -157,6 +170,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": launches,
+                         "concurrent_streams": ns,
+                         "isolated": {"achieved": iso_tf, "frac": iso_tf / F32_MFMA_PEAK_TFLOPS, "avg_launch_ms": iso_ms,
+                                      "images_per_launch": b0, "note": "same kernel, one sub-batch alone on the GPU (single stream)"},
                          "ec_hidden_ms_per_step": ec_t / args.steps, "dc_hidden_ms_per_step": dc_t / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
