@@ -160,6 +160,13 @@ def main():
         iso_flops = 2 * HIDDEN_GMAC * 1e9 * b0 * 10 / max(iso["dc_launches"] if dc_t >= ec_t else iso["ec_launches"], 1)
         iso_tf = iso_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["dominant_kernel"]
+            if dc_t >= ec_t:
+                traffic = pm["traffic_bytes_per_launch"] * (B / float(ns)) / pm["images_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "ERP Mpixels/s enc+dec @512x1024 model-idx 3; bitstream bit-exact vs ref",
             "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,7 +176,7 @@ def main():
                                    "model-idx 3 --ssim seeded weights, latent entropy encode+decode (BASELINE.json configs[3] per-GPU share)" % B,
                        "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean())},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": launches,
                          "concurrent_streams": ns,
                          "isolated": {"achieved": iso_tf, "frac": iso_tf / F32_MFMA_PEAK_TFLOPS, "avg_launch_ms": iso_ms,
