@@ -39,16 +39,17 @@ static inline bool conv4_ok(const lic360_conv_plan *p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// packed4[net][g][tc][c][tq][r][j]: class c = virtual lane mod 4, leaf i = tq*4+j inside the class
-// (cin = 4: tap = i, gid = (c - tap) mod 4;  cin = 1: tap = c + 4*i), r = output channel within the group
+// packed4[net][g][tc][c][leaf][r]: class c = virtual lane mod 4, leaf i (0..31) inside the class
+// (cin = 4: tap = i, gid = (c - tap) mod 4;  cin = 1: tap = c + 4*i), r = output channel within the group.
+// A wave reads its class as two 64-float registers: lane (i%16)*4 + r of register i/16 holds the weight of leaf i, row r --
+// exactly the 4-lane block that `abid = i%16` selects for broadcast (cbsz = 4) in v_mfma_f32_4x4x1_16b_f32.
 __global__ void k_conv4_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int ngroup, int cin, int cout, int hidden) {
     const long per_net = (long)ngroup * ngroup * C4_WSLOTS * 4, total = per_net * nb;
     const int C = ngroup * cin, nout = ngroup * cout;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int j = (int)(i & 3), r = (int)((i >> 2) & 3), tq = (int)((i >> 4) & 7), c = (int)((i >> 7) & 3);
+        int r = (int)(i & 3), leaf = (int)((i >> 2) & 31), c = (int)((i >> 7) & 3);
         long t = i / (C4_WSLOTS * 4);
         int tc = (int)(t % ngroup), g = (int)((t / ngroup) % ngroup), b = (int)(t / ((long)ngroup * ngroup));
-        int leaf = tq * 4 + j;
         int tap = cin == 4 ? leaf : c + 4 * leaf, gid = cin == 4 ? ((c - tap) & 3) : 0;
         float v = 0.0f;
         if (tap < 25 && r < cout) {
@@ -98,70 +99,43 @@ struct Tree4<CIN, I, 128> {
 
 template <int CIN> struct NAcc { static constexpr int value = CIN == 4 ? 25 : 7; };
 
-// one K step of lane class CLS: every active lane gets  acc = fma(w, x, acc).
+// one K step of lane class CLS: every lane gets  acc = fma(w, x, acc)  (lanes whose chain has ended carry w = 0).
 // DIAG: staged tile rows are anti-diagonals (row = kh+kw, col = kh + lane) instead of image rows (row = kh, col = kw + lane).
-// A lane (tap kh,kw) is active in this step iff kh+kw < dlim.  While dlim >= 9 every lane is active and the step is one
-// straight-line block (all LDS reads can be hoisted above the 25 MFMAs); the last <= 8 steps of a chain run tap groups of
-// equal kh+kw under one scalar branch each.
-template <int CIN, int CLS, int I, int XPLANE, int COLS, bool DIAG>
-struct LaneOf {
-    static constexpr int tap = CIN == 4 ? I : CLS + 4 * I;
-    static constexpr bool valid = tap < 25;
-    static constexpr int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
-    static constexpr int xoff = gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw);
-};
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);   // D = fma(A[block ABID], B, C), A broadcast to all 16 blocks
+}
+template <int I> struct IC { static constexpr int value = I; };
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(IC<I>{}); static_for<N, F, I + 1>(static_cast<F &&>(f)); }
+}
 
 template <int CIN, int CLS, int XPLANE, int COLS, bool DIAG, bool FULL>
 __device__ __forceinline__ void conv4_step(f32x4 *acc, const float *xs, const f32x4 *ws4, int dlim, int lane, int xbase) {
     constexpr int NA = NAcc<CIN>::value;
-    const f32x4 *wl = ws4 + CLS * 32 + (lane & 3);
+    static_assert(FULL, "every step is a full straight-line step (zero weights past a lane's chain end)");
+    (void)dlim;
+    // the class's weights for this step: 2 registers of 16 leaves x 4 rows (2 ds_read_b32 instead of 7 ds_read_b128)
+    const float *wl = (const float *)ws4 + CLS * 128 + lane;
+    const float w0 = wl[0], w1 = NA > 16 ? wl[64] : 0.0f;
     const float *xl = xs + xbase;
-    if constexpr (FULL) {
-        // three register-bounded chunks (8 lanes each): reads of a chunk are issued together, then its MFMAs
-        constexpr int CH = 8;
-#pragma unroll
-        for (int c0 = 0; c0 < NA; c0 += CH) {
-            f32x4 a4[2];
-            float bv[CH];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) a4[q] = wl[(c0 / 4 + q) * 4];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;       // compile-time after unrolling
-                const int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
-                bv[k] = (i < NA && tap < 25) ? xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)] : 0.0f;
-            }
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
-                if (i < NA && tap < 25) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[k / 4][k % 4], bv[k], acc[i], 4, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < 9; ++d) {
-            if (d < dlim) {
-                f32x4 a4[(NA + 3) / 4];
-                float bv[NA];
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int tap = CIN == 4 ? i : CLS + 4 * i;
-                    const int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
-                    if (tap < 25 && kh + kw == d) {
-                        a4[i / 4] = wl[(i / 4) * 4];
-                        bv[i] = xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int tap = CIN == 4 ? i : CLS + 4 * i;
-                    const int kh = tap / 5, kw = tap % 5;
-                    if (tap < 25 && kh + kw == d) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[i / 4][i % 4], bv[i], acc[i], 4, 0, 0);
-                }
-            }
-        }
-    }
+    // register-bounded chunks of 8 lanes: the LDS reads of a chunk are issued together, then its MFMAs
+    constexpr int CH = 8;
+    static_for<(NA + CH - 1) / CH>([&](auto cc) {
+        constexpr int c0 = decltype(cc)::value * CH;
+        float bv[CH];
+        static_for<CH>([&](auto kk) {
+            constexpr int k = decltype(kk)::value, i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
+            constexpr int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
+            if constexpr (i < NA && tap < 25) bv[k] = xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
+        });
+        static_for<CH>([&](auto kk) {
+            constexpr int k = decltype(kk)::value, i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
+            if constexpr (i < NA && tap < 25) acc[i] = mfma4<i % 16>(i < 16 ? w0 : w1, bv[k], acc[i]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 #define C4_PS 3                          // position sets (rows / diagonals) per workgroup
