@@ -111,30 +111,35 @@ __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(IC<I>{}); static_for<N, F, I + 1>(static_cast<F &&>(f)); }
 }
 
-template <int CIN, int CLS, int XPLANE, int COLS, bool DIAG, bool FULL>
+// PART 0 = the first chunk of 8 accumulators, PART 1 = the rest, PART 2 = everything.  The persistent kernels run part 0,
+// then stage the NEXT step (global loads, ds_writes into the other LDS half), then part 1: the staging instructions
+// issue in the shadow of the first chunk's MFMAs instead of in front of them.
+template <int CIN, int CLS, int XPLANE, int COLS, bool DIAG, bool FULL, int PART = 2>
 __device__ __forceinline__ void conv4_step(f32x4 *acc, const float *xs, const f32x4 *ws4, int dlim, int lane, int xbase) {
     constexpr int NA = NAcc<CIN>::value;
     static_assert(FULL, "every step is a full straight-line step (zero weights past a lane's chain end)");
     (void)dlim;
     // the class's weights for this step: 2 registers of 16 leaves x 4 rows (2 ds_read_b32 instead of 7 ds_read_b128)
     const float *wl = (const float *)ws4 + CLS * 128 + lane;
-    const float w0 = wl[0], w1 = NA > 16 ? wl[64] : 0.0f;
+    const float w0 = wl[0], w1 = (NA > 16 && PART != 0) ? wl[64] : 0.0f;
     const float *xl = xs + xbase;
     // register-bounded chunks of 8 lanes: the LDS reads of a chunk are issued together, then its MFMAs
     constexpr int CH = 8;
     static_for<(NA + CH - 1) / CH>([&](auto cc) {
         constexpr int c0 = decltype(cc)::value * CH;
-        float bv[CH];
-        static_for<CH>([&](auto kk) {
-            constexpr int k = decltype(kk)::value, i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
-            constexpr int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
-            if constexpr (i < NA && tap < 25) bv[k] = xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
-        });
-        static_for<CH>([&](auto kk) {
-            constexpr int k = decltype(kk)::value, i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
-            if constexpr (i < NA && tap < 25) acc[i] = mfma4<i % 16>(i < 16 ? w0 : w1, bv[k], acc[i]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PART == 2 || (PART == 0) == (c0 == 0)) {
+            float bv[CH];
+            static_for<CH>([&](auto kk) {
+                constexpr int k = decltype(kk)::value, i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
+                constexpr int kh = tap / 5, kw = tap % 5, gid = CIN == 4 ? ((CLS - tap) & 3) : 0;
+                if constexpr (i < NA && tap < 25) bv[k] = xl[gid * XPLANE + (DIAG ? (kh + kw) * COLS + kh : kh * COLS + kw)];
+            });
+            static_for<CH>([&](auto kk) {
+                constexpr int k = decltype(kk)::value, i = c0 + k, tap = CIN == 4 ? i : CLS + 4 * i;
+                if constexpr (i < NA && tap < 25) acc[i] = mfma4<i % 16>(i < 16 ? w0 : w1, bv[k], acc[i]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
     });
 }
 
@@ -260,6 +265,7 @@ LIC360_API int lic360_cconv4_ec(void *stream, const lic360_conv_plan *p, const f
 
 // ------------------------------------------------------------------------------------------------ DC4
 #include "cconv4v3_dc.inc"
+#include "cconv4v6_dc.inc"
 #include "cconv4v3_ec.inc"
 
 LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
@@ -267,7 +273,11 @@ LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, c
     ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
     ARG_CHECK(h <= 64 || w <= 64);                                      // an anti-diagonal must fit one wave (64 positions)
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
-    return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
+    {
+        const char *v = getenv("LIC360_DC4");                           // "3" selects the LDS-DMA kernel (A/B runs)
+        if (h > 64 || (v && v[0] == '3')) return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
+    }
+    return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
 }
 
 LIC360_API int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0) {
