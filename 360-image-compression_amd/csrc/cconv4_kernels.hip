@@ -292,6 +292,19 @@ LIC360_API int lic360_ec4_layout(int h, int w, int *hp, int *wp) {
     *hp = E3_HP(h); *wp = E3_WP(w);
     return 0;
 }
+// encode order on the wrapped diagonal-major layout (cconv4v6_dc.inc): planes of `rows` x `pitch` floats, cell (th, tw) on
+// wrapped diagonal sg = (th + tw + 2) % wpp at [(sg + row0) * pitch + th + 2]; diagonals < rows - wpp - row0 are stored a
+// second time wpp rows further down and diagonals >= wpp - row0 a second time wpp rows further up.
+LIC360_API int lic360_ec6_layout(int h, int w, int *rows, int *pitch, int *row0, int *wpp) {
+    ARG_CHECK(h > 0 && h <= 64 && w >= 7 && rows && pitch && row0 && wpp);             // the 11-row band must not overlap itself
+    *rows = E6_ROWS(w); *pitch = D3_HP(h); *row0 = E6_R0; *wpp = E6_WPP(w);
+    return 0;
+}
+LIC360_API int lic360_cconv4_ec_diag(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                     const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod) {
+    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && h > 0 && h <= 64 && w >= 7 && x_mod > 0);
+    return launch_cconv4v6_ec((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, x_mod);
+}
 LIC360_API int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                        const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod) {
     ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);

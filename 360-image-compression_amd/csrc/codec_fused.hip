@@ -27,7 +27,8 @@ struct AcDevState {            // per-image decoder state carried across planes
 struct lic360_codec {
     int G, H, W, maxB, S, P, HW;
     int sk_rows, sk_pitch, sk_row0, sk_col0;
-    int e_hp, e_wp, e_off;                     // encode activation planes: [e_hp][e_wp], cell (r, c) at [(r+e_off)*e_wp + c+e_off]   // diagonal-major decode layout: cell (s, th) at [(s + row0) * pitch + th + col0]
+    int e_hp, e_wp, e_off;                     // encode activation planes: [e_hp][e_wp], cell (r, c) at [(r+e_off)*e_wp + c+e_off]
+    int e_wpp = 0;                             // > 0: wrapped diagonal-major planes instead (lic360_ec6_layout): [e_hp rows][e_wp = h+4]   // diagonal-major decode layout: cell (s, th) at [(s + row0) * pitch + th + col0]
     lic360_conv_plan *plan[3];                 // first, hidden, last
     float *packed[12], *bias[12], *act[12];
     float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
@@ -61,12 +62,26 @@ static int plan_of(int layer) { return layer == 0 ? 0 : (layer == 11 ? 2 : 1); }
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // ------------------------------------------------------------------------------------------------ encode
+// offset of cell (r, c) inside one encode activation plane; wpp > 0 selects the wrapped diagonal-major layout, whose
+// first / last diagonals are stored twice (*dup = offset of the second copy, or -1)
+__device__ __forceinline__ long e_cell(int r, int c, int hp, int wp, int off, int wpp, long *dup) {
+    *dup = -1;
+    if (wpp == 0) return (long)(r + off) * wp + c + off;
+    const int sg = (r + c + 2) % wpp, r0 = off;                             // off carries the row of diagonal 0
+    if (sg < hp - wpp - r0) *dup = (long)(sg + r0 + wpp) * wp + r + 2;
+    else if (sg >= wpp - r0) *dup = (long)(sg + r0 - wpp) * wp + r + 2;
+    return (long)(sg + r0) * wp + r + 2;
+}
+
 __global__ void k_enc_prep(const float *__restrict__ code, const float *__restrict__ mask, float *__restrict__ x0, long total,
-                           int H, int W, int hp, int wp, int off) {
+                           int H, int W, int hp, int wp, int off, int wpp) {
     GRID_STRIDE(i, total) {
         int c = (int)(i % W), r = (int)((i / W) % H);
-        long pl = i / ((long)H * W);
-        x0[(pl * hp + r + off) * wp + c + off] = (code[i] - 3.5f) * mask[i];        // lic360_demo.py:130
+        long pl = i / ((long)H * W), dup;
+        const long o = e_cell(r, c, hp, wp, off, wpp, &dup);
+        const float v = (code[i] - 3.5f) * mask[i];                                  // lic360_demo.py:130
+        x0[pl * hp * wp + o] = v;
+        if (dup >= 0) x0[pl * hp * wp + dup] = v;
     }
 }
 
@@ -91,7 +106,7 @@ __device__ __forceinline__ void gmm_cdf9(const float *lw_in, const float *ld_in,
 // plane, rows ascending inside a diagonal (extension/code_contex_cuda.cu:19-31, tile_extract_cuda.cu:36-41).
 __global__ void k_enc_tables(const float *__restrict__ y, const float *__restrict__ code, const float *__restrict__ mask,
                              const int *__restrict__ pidx, const int *__restrict__ plane_start, uint2 *__restrict__ rec,
-                             int B, int G, int H, int W, int hp, int wp, int off) {
+                             int B, int G, int H, int W, int hp, int wp, int off, int wpp) {
     const long HW = (long)H * W, per = (long)G * HW, total = per * B;
     GRID_STRIDE(i, total) {
         int tw = (int)(i % W), th = (int)((i / W) % H), g = (int)((i / HW) % G), b = (int)(i / per);
@@ -101,11 +116,13 @@ __global__ void k_enc_tables(const float *__restrict__ y, const float *__restric
         uint2 r = make_uint2(0u, 0u);
         if (!(mask[i] < 0.5f)) {                                     // coder.cpp:79
             float v[9];
+            long dup;
+            const long cell = e_cell(th, tw, hp, wp, off, wpp, &dup);
 #pragma unroll
             for (int net = 0; net < 3; ++net)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    v[net * 3 + c] = y[(((long)(net * B + b) * (3 * G) + g * 3 + c) * hp + th + off) * wp + tw + off];
+                    v[net * 3 + c] = y[((long)(net * B + b) * (3 * G) + g * 3 + c) * hp * wp + cell];
             int T[9];
             gmm_cdf9(v, v + 3, v + 6, T);
             int sym = (int)code[i];
@@ -308,7 +325,10 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     if (c->use4) { if (lic360_dc4_layout(h, w, &c->sk_rows, &c->sk_pitch, &c->sk_row0, &c->sk_col0)) return 1; }
     else { c->sk_rows = c->S; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
     const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = 4096;   // TAIL: band fetches may run past the last row
-    if (c->use4) { if (lic360_ec4_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
+    const char *force_ec = getenv("LIC360_EC4");                       // "3" keeps the row-major LDS-DMA encode kernel (A/B runs)
+    if (c->use4 && h <= 64 && w >= 7 && !(force_ec && force_ec[0] == '3')) {
+        if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
+    } else if (c->use4) { if (lic360_ec4_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else { c->e_hp = h; c->e_wp = w; c->e_off = 0; }
     const size_t EPL = (size_t)c->e_hp * c->e_wp;
     rc |= dmalloc(&c->e_x0, B * G * EPL + TAIL);
@@ -373,11 +393,12 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     hipStream_t s = (hipStream_t)stream;
     const int G = c->G, H = c->H, W = c->W;
     const long total = (long)B * G * c->HW;
-    hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total, H, W, c->e_hp, c->e_wp, c->e_off);
+    hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp);
     LAUNCH_CHECK();
     float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
     auto ec = [&](int layer, const float *xin, const float *res, float *dst, int x_mod) -> int {
         lic360_conv_plan *p = c->plan[plan_of(layer)];
+        if (c->e_wpp) return lic360_cconv4_ec_diag(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
         if (c->use4) return lic360_cconv4_ec_padded(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
         return lic360_cconv_ec_ex(stream, p, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
     };
@@ -394,7 +415,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     }
     if (ec(11, cur, nullptr, t1, 3 * B)) return 1;
     hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx, c->d_plane_start,
-                       c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off);
+                       c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err);
     LAUNCH_CHECK();

@@ -8,9 +8,12 @@ GPUs with no data-path collective: every rank runs the same per
 the only cross-rank traffic is the barrier + MAX of the wall time.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with
-  roofline:     dominant kernel = the hidden-layer masked conv (encode-order k_cconv_ec or decode-order
-                k_cconv_dc, whichever took more time); achieved = algorithmic FLOPs per launch / mean launch
-                duration from HIP events recorded on the launch stream during the timed steps;
+  roofline:     dominant kernel = the hidden-layer masked conv (encode order or decode order, whichever took more
+                time).  Its binding roofline is the fp32 MFMA peak: the MACs of a launch take longer at 157 TFLOP/s
+                than its algorithmic bytes (the 9-diagonal halo of every live group, read once) take at 8 TB/s.
+                achieved = algorithmic FLOPs per launch / mean launch duration from HIP events recorded on the
+                launch stream during the timed steps; the HBM view of the same launches (algorithmic bytes and the
+                measured PMC traffic) is reported next to it;
   cpu_baseline: the CPU oracle (oracle/, OpenMP over output scalars) on a bounded crop of the same workload.
 """
 import argparse
@@ -35,7 +38,45 @@ PIXELS = 512 * 1024
 MODEL_IDX, SSIM = 3, 1
 # algorithmic work per image, exact counts from the mask rule (SURVEY.md §8d / BASELINE.md §3)
 HIDDEN_GMAC = 11.23                     # one hidden layer, 3 stacked nets
-F32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+F32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 MFMA dense peak
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def chain_len(g, hidden=1):
+    """input groups group g reads in a hidden layer (extension/cconv_ec_cuda.cu:288-290, longest lane)"""
+    return min(G, g + 4 + hidden)
+
+
+def dc_hidden_bytes_per_launch(b):
+    """Algorithmic HBM bytes of one decode-order hidden-layer launch (one anti-diagonal plane, 3*b sample-nets), averaged
+    over the planes: every input (channel, diagonal) a live group needs is read once, every output written once, half of
+    the hidden layers read a residual, the weights of the live groups are read once."""
+    S, n = H + W - 1, 3 * b
+    lens = [min(s, H - 1) - max(0, s - W + 1) + 1 for s in range(S)]
+    tot, launches = 0.0, 0
+    for p in range(S + G - 1):
+        live = [g for g in range(G) if 0 <= p - g < S]
+        if not live:
+            continue
+        launches += 1
+        inb = 0
+        for tc in range(G):
+            rows = set()
+            for g in live:
+                if tc < chain_len(g):
+                    rows.update(s for s in range(p - g - 4, p - g + 5) if 0 <= s < S)
+            inb += 4 * sum(lens[s] for s in rows)
+        outb = sum(4 * lens[p - g] for g in live)
+        wb = 3 * sum(chain_len(g) * 400 for g in live)
+        tot += 4.0 * (n * (inb + 1.5 * outb) + wb)
+    return tot / launches
+
+
+def ec_hidden_bytes_per_launch(b):
+    """Algorithmic HBM bytes of one encode-order hidden-layer launch: activations in, activations out (+ residual for
+    half of the layers), weights once."""
+    n = 3 * b
+    return 4.0 * (n * 4 * G * H * W * 2.5 + 3 * sum(chain_len(g) * 400 for g in range(G)))
 
 
 def synth_latents(batch, seed0):
@@ -148,23 +189,27 @@ def main():
         nbytes = np.concatenate([c.nbytes[:cd.shape[0]].cpu().numpy() for c, cd in zip(codecs, codes)])
         # dominant kernel: hidden-layer masked conv, encode order vs decode order
         ec_t, dc_t = prof["ec_ms"], prof["dc_ms"]
-        if dc_t >= ec_t:
-            name, tot_ms, launches = "k_cconv4v3_dc<4> (decode order, hidden layers)", dc_t, prof["dc_launches"]
-            flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)   # all hidden DC launches of a step cover B images x 10 layers
+        b0 = int(codes[0].shape[0])                        # images per launch (one sub-batch)
+        dom_dc = dc_t >= ec_t
+        if dom_dc:
+            name, tot_ms, launches = "k_cconv4v6<4, false> (decode order, hidden layers)", dc_t, prof["dc_launches"]
+            iso_ms = iso["dc_ms"] / max(iso["dc_launches"], 1)
+            bytes_per_launch = dc_hidden_bytes_per_launch(b0)
         else:
-            name, tot_ms, launches = "k_cconv4v3_ec<4> (encode order, hidden layers)", ec_t, prof["ec_launches"]
-            flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)
+            name, tot_ms, launches = "k_cconv4v6<4, true> (encode order, hidden layers)", ec_t, prof["ec_launches"]
+            iso_ms = iso["ec_ms"] / max(iso["ec_launches"], 1)
+            bytes_per_launch = ec_hidden_bytes_per_launch(b0)
+        flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)   # all hidden launches of a step cover B images x 10 layers
         avg_ms = tot_ms / max(launches, 1)
-        b0 = int(codes[0].shape[0])
-        iso_ms = (iso["dc_ms"] / max(iso["dc_launches"], 1)) if dc_t >= ec_t else (iso["ec_ms"] / max(iso["ec_launches"], 1))
-        iso_flops = 2 * HIDDEN_GMAC * 1e9 * b0 * 10 / max(iso["dc_launches"] if dc_t >= ec_t else iso["ec_launches"], 1)
-        iso_tf = iso_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        iso_gbs = bytes_per_launch / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
+        tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        iso_tf = flops_per_launch / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
         traffic = None
         try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["dominant_kernel"]
-            if dc_t >= ec_t:
-                traffic = pm["traffic_bytes_per_launch"] * (B / float(ns)) / pm["images_per_launch"]
+            if dom_dc:
+                traffic = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
         except Exception:
             traffic = None
         out = {
@@ -175,12 +220,16 @@ def main():
             "config": {"workload": "batch of %d synthetic 512x1024 ERP latents per GPU (48x64x128 symbols + importance mask), "
                                    "model-idx 3 --ssim seeded weights, latent entropy encode+decode (BASELINE.json configs[3] per-GPU share)" % B,
                        "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean())},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": launches,
-                         "concurrent_streams": ns,
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "algorithmic_flops_per_launch": flops_per_launch, "images_per_launch": b0,
+                         "avg_launch_ms": avg_ms, "launches": launches, "concurrent_streams": ns,
                          "isolated": {"achieved": iso_tf, "frac": iso_tf / F32_MFMA_PEAK_TFLOPS, "avg_launch_ms": iso_ms,
-                                      "images_per_launch": b0, "note": "same kernel, one sub-batch alone on the GPU (single stream)"},
+                                      "note": "same kernel, one sub-batch alone on the GPU (single stream); in the timed run "
+                                              "kernels of the other streams share the CUs and stretch each launch"},
+                         "hbm": {"algorithmic_bytes_per_launch": bytes_per_launch, "achieved": achieved, "isolated": iso_gbs,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "frac_isolated": iso_gbs / HBM_PEAK_GBS},
                          "ec_hidden_ms_per_step": ec_t / args.steps, "dc_hidden_ms_per_step": dc_t / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -138,6 +138,14 @@ int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0)
 int lic360_ec4_layout(int h, int w, int *hp, int *wp);
 int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
                             const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
+/* encode order on wrapped diagonal-major planes (h <= 64): `rows` x `pitch` floats per channel, cell (th, tw) on wrapped
+ * diagonal sg = (th + tw + 2) % wpp at [(sg + row0) * pitch + th + 2]; diagonals sg < rows - wpp - row0 are stored a second
+ * time at row sg + row0 + wpp, diagonals sg >= wpp - row0 a second time at row sg + row0 - wpp (so that the 11-row halo band
+ * of any position set is contiguous); everything else stays zero.  Same arithmetic as lic360_cconv_ec
+ * (extension/cconv_ec_cuda.cu:271-331), one LDS read per tap diagonal. */
+int lic360_ec6_layout(int h, int w, int *rows, int *pitch, int *row0, int *wpp);
+int lic360_cconv4_ec_diag(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
+                          const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
 int lic360_conv4_supported(const lic360_conv_plan *plan);
 long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);

@@ -337,3 +337,60 @@ def test_cconv4_ec_bit_exact(lic, case):
     got = host(out)
     L.lic360_conv_plan_destroy(plan)
     assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
+
+
+def _ec6_maps(L, H, W):
+    import ctypes as C
+    rows, pitch, row0, wpp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert L.lic360_ec6_layout(H, W, C.byref(rows), C.byref(pitch), C.byref(row0), C.byref(wpp)) == 0
+    rows, pitch, row0, wpp = rows.value, pitch.value, row0.value, wpp.value
+    th, tw = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    sg = (th + tw + 2) % wpp
+    return rows, pitch, row0, wpp, th, tw, sg
+
+
+def _to_ec6(x, maps):
+    rows, pitch, row0, wpp, th, tw, sg = maps
+    out = np.zeros(x.shape[:2] + (rows, pitch), np.float32)
+    out[:, :, sg + row0, th + 2] = x
+    lo = sg < rows - wpp - row0
+    out[:, :, (sg + row0 + wpp)[lo], (th + 2)[lo]] = x[:, :, th[lo], tw[lo]]
+    hi = sg >= wpp - row0
+    out[:, :, (sg + row0 - wpp)[hi], (th + 2)[hi]] = x[:, :, th[hi], tw[hi]]
+    return out
+
+
+@pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 7, 70), (6, 4, 4, True, True, 3, 3, 5, 66), (48, 4, 4, True, True, 3, 3, 3, 64),
+                                  (48, 4, 3, True, False, 3, 6, 4, 20), (9, 4, 4, True, True, 1, 2, 64, 9), (7, 1, 4, False, False, 1, 1, 33, 40)],
+                         ids=lambda c: "g%d_%dto%d_%dx%d" % (c[0], c[1], c[2], c[7], c[8]))
+def test_cconv4_ec_diag_bit_exact(lic, case):
+    """encode-order conv on the wrapped diagonal-major layout (lic360_cconv4_ec_diag) == oracle, incl. the duplicated rows"""
+    import ctypes as C
+    G, cin, cout, hidden, act, nb, N, H, W = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    Cc, nout = G * cin, G * cout
+    w, b, a = conv_params(rng, nb, nout, Cc, act=act)
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
+    constrain = 6 if hidden else 5
+    ref = orc.cconv_ec(x, w, b, a, G, constrain) + res
+    L = lic._lib
+    maps = _ec6_maps(L, H, W)
+    plan = C.c_void_p(0)
+    assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
+    L.lic360_conv4_packed_floats.restype = C.c_long
+    L.lic360_conv4_packed_floats.argtypes = [C.c_void_p]
+    packed = torch.empty(nb * L.lic360_conv4_packed_floats(plan), dtype=torch.float32, device="cuda:0")
+    tail = torch.zeros(4096, dtype=torch.float32, device="cuda:0")                     # band fetches may run past the last row
+    xd = torch.cat([dev(_to_ec6(x, maps)).flatten(), tail])
+    rd = torch.cat([dev(_to_ec6(res, maps)).flatten(), tail])
+    wd, bd = dev(w), dev(b)
+    ad = dev(a) if act else None
+    out = torch.zeros(N * nout * maps[0] * maps[1] + 4096, dtype=torch.float32, device="cuda:0")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    assert L.lic360_conv4_pack(s, plan, P(wd), nb, P(packed)) == 0
+    assert L.lic360_cconv4_ec_diag(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, N) == 0, L.lic360_last_error()
+    got = host(out)[:N * nout * maps[0] * maps[1]].reshape(N, nout, maps[0], maps[1])
+    L.lic360_conv_plan_destroy(plan)
+    assert np.array_equal(got, _to_ec6(ref, maps)), "wrapped-diagonal output (with its repeated rows and zero padding) differs"
