@@ -39,6 +39,8 @@ struct lic360_codec {
     uint2 *e_rec;
     float *d_x0, *d_act[11], *d_y;
     AcDevState *d_state;
+    uint4 *d_tab = nullptr;                    // per-plane CDF tables [maxB][tab_pitch] (k_dec_tables -> k_dec_plane)
+    int tab_pitch = 0;
     bool layer_set[12];
     // optional per-kernel timing of the hidden-layer conv launches (bench.py roofline leg)
     bool prof = false;
@@ -210,13 +212,45 @@ struct DevBits {
     }
 };
 
-// One wave per image and plane: tables for 64 plane positions in parallel, serial range decode on the
-// wave-uniform state, then scatter of (sym-3.5 | 0) into the diagonal-major input of the next plane and
-// of the decoded symbol into the NCHW output (= TileInput + `b[0:1] + 3.5*mask`, lic360_demo.py:222,236-237).
-__global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, const float *__restrict__ mask, const int *__restrict__ idx,
+// Decode of one plane runs as two kernels:
+//  k_dec_tables -- one thread per (image, plane position): the 7 inner CDF entries of the symbol from the three nets' outputs,
+//                  7 x int32 + a "coded" flag as two uint4 (massively parallel, register-hungry, short);
+//  k_dec_plane  -- one wave per image: serial range decode on the wave-uniform state from those tables, then scatter of
+//                  (sym-3.5 | 0) into the diagonal-major input of the next plane and of the decoded symbol into the NCHW
+//                  output (= TileInput + `b[0:1] + 3.5*mask`, lic360_demo.py:222,236-237).  It needs < 40 VGPRs, so its
+//                  waves fit next to the 12-wave workgroups of the conv kernels of the other streams (456 of 512 VGPRs
+//                  per SIMD) instead of keeping whole CUs away from them for the ~0.4 ms the serial chain takes.
+__global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, const float *__restrict__ mask, const int *__restrict__ idx,
+                                                   int start, int len, int p, uint4 *__restrict__ tab, int tab_pitch,
+                                                   int B, int G, int H, int W, int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
+    const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= len) return;
+    const int HW = H * W;
+    const long SK = (long)sk_rows * sk_pitch;
+    const int q = start + i;
+    const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
+    const long nchw = (((long)b * G + g) * H + th) * W + tw;
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+    if (!(mask[nchw] < 0.5f)) {                                      // coder.cpp:79
+        float v[9];
+#pragma unroll
+        for (int net = 0; net < 3; ++net)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[net * 3 + c] = y[((long)(net * B + b) * (3 * G) + g * 3 + c) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0];
+        int T[9];
+        gmm_cdf9(v, v + 3, v + 6, T);                                // 0 = T[0] < T[1] < ... < T[8] = 65536
+        r0 = make_uint4((unsigned)T[1], (unsigned)T[2], (unsigned)T[3], (unsigned)T[4]);
+        r1 = make_uint4((unsigned)T[5], (unsigned)T[6], (unsigned)T[7], 1u);
+    }
+    tab[((long)b * tab_pitch + i) * 2] = r0;
+    tab[((long)b * tab_pitch + i) * 2 + 1] = r1;
+}
+
+__global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab, int tab_pitch, const int *__restrict__ idx,
                                                   int start, int len, int p, AcDevState *__restrict__ state,
                                                   const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes,
-                                                  float *__restrict__ x0, float *__restrict__ code_out, int B, int G, int H, int W,
+                                                  float *__restrict__ x0, float *__restrict__ code_out, int G, int H, int W,
                                                   int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int HW = H * W;
@@ -230,43 +264,34 @@ __global__ __launch_bounds__(64) void k_dec_plane(const float *__restrict__ y, c
     for (int base = 0; base < len; base += 64) {
         const int cnt = (len - base) < 64 ? (len - base) : 64;
         const bool live = lane < cnt;
-        const int q = start + base + (live ? lane : 0);
-        const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
-        const long nchw = (((long)b * G + g) * H + th) * W + tw;
-        const bool coded = live && !(mask[nchw] < 0.5f);
-        int T[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) T[k] = 0;
-        if (coded) {
-            float v[9];
-#pragma unroll
-            for (int net = 0; net < 3; ++net)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    v[net * 3 + c] = y[((long)(net * B + b) * (3 * G) + g * 3 + c) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0];
-            gmm_cdf9(v, v + 3, v + 6, T);
-        }
+        uint4 ta = make_uint4(0u, 0u, 0u, 0u), tb = ta;
+        if (live) { ta = tab[((long)b * tab_pitch + base + lane) * 2]; tb = tab[((long)b * tab_pitch + base + lane) * 2 + 1]; }
+        const bool coded = tb.w != 0u;
         const unsigned long long cmask = __ballot(coded);
         int symv = 0;
         for (int j = 0; j < cnt; ++j) {
             if (!((cmask >> j) & 1ull)) continue;
-            int t[9];
-            t[0] = 0; t[8] = 65536;
-#pragma unroll
-            for (int k = 1; k < 8; ++k) t[k] = __builtin_amdgcn_readlane(T[k], j);
-            uint32_t target = ac_decode_target(st, 65536u);
+            uint32_t t[9];
+            t[0] = 0; t[8] = 65536u;
+            t[1] = (uint32_t)__builtin_amdgcn_readlane((int)ta.x, j); t[2] = (uint32_t)__builtin_amdgcn_readlane((int)ta.y, j);
+            t[3] = (uint32_t)__builtin_amdgcn_readlane((int)ta.z, j); t[4] = (uint32_t)__builtin_amdgcn_readlane((int)ta.w, j);
+            t[5] = (uint32_t)__builtin_amdgcn_readlane((int)tb.x, j); t[6] = (uint32_t)__builtin_amdgcn_readlane((int)tb.y, j);
+            t[7] = (uint32_t)__builtin_amdgcn_readlane((int)tb.z, j);
+            const uint32_t target = ac_decode_target(st, 65536u);
             int sym = 0;
 #pragma unroll
-            for (int k = 1; k < 8; ++k) sym += (target >= (uint32_t)t[k]) ? 1 : 0;
+            for (int k = 1; k < 8; ++k) sym += (target >= t[k]) ? 1 : 0;
             uint32_t lo = 0, hi = 65536;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if (sym == k) { lo = (uint32_t)t[k]; hi = (uint32_t)t[k + 1]; }
+            for (int k = 0; k < 8; ++k) if (sym == k) { lo = t[k]; hi = t[k + 1]; }
             ac_decode_consume_from(st, rd, lo, hi, 65536u);
             symv = (lane == j) ? sym : symv;
         }
         if (live) {
+            const int q = start + base + lane;
+            const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
             x0[((long)b * G + g) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0] = coded ? (float)symv - 3.5f : 0.0f;
-            code_out[nchw] = coded ? (float)symv : 0.0f;
+            code_out[(((long)b * G + g) * H + th) * W + tw] = coded ? (float)symv : 0.0f;
         }
     }
     if (lane == 0) {
@@ -338,6 +363,9 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], 3 * B * 4 * G * SK + TAIL);
     rc |= dmalloc(&c->d_y, 3 * B * 3 * G * SK + TAIL);
     rc |= dmalloc(&c->d_state, B);
+    for (int p = 0; p < c->P; ++p) c->tab_pitch = std::max(c->tab_pitch, c->h_plane_start[p + 1] - c->h_plane_start[p]);
+    c->tab_pitch = (c->tab_pitch + 63) / 64 * 64;
+    rc |= dmalloc(&c->d_tab, 2 * B * (size_t)c->tab_pitch);
     if (rc) return 1;
     // decode activations are only ever read where already written or with a zero weight; they must be finite
     HIP_TRY(hipMemset(c->e_x0, 0, (B * G * EPL + TAIL) * 4));
@@ -356,7 +384,7 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->d_plane_start);
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
-    (void)hipFree(c->d_y); (void)hipFree(c->d_state);
+    (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab);
     delete c;
 }
 
@@ -452,8 +480,12 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
         if (dc(11, c->d_act[10], nullptr, c->d_y, 3 * B, p)) return 1;
         int start, len;
         lic360_plane_window(p, G, H, W, pih, &start, &len);
-        hipLaunchKernelGGL(k_dec_plane, dim3(B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
-                           c->d_x0, code_out, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        if (len <= 0) continue;
+        hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_tab, c->tab_pitch,
+                           B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_dec_plane, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
+                           c->d_x0, code_out, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
