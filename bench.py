@@ -103,7 +103,25 @@ def cpu_baseline(layers):
     dt = time.time() - t0
     px = reps * PIXELS * (ch * cw) / float(H * W)
     cores = int(os.environ["OMP_NUM_THREADS"])
+    # single-thread arithmetic coder alone: config-1 workload, 393 216 symbols on per-symbol 9-entry tables
+    import oracle as orc
+    rng = np.random.default_rng(5)
+    nsym = G * H * W
+    inner = np.sort(rng.integers(1, 65535, (nsym, 7)), axis=1) + np.arange(7)
+    tab = np.concatenate([np.zeros((nsym, 1), np.int64), inner, np.full((nsym, 1), 65536 + 7, np.int64)], 1).astype(np.int32)
+    sym = rng.integers(0, 8, nsym).astype(np.int32)
+    t1 = time.time()
+    enc = orc.Encoder()
+    enc.encode(tab, 8, sym, None, nsym)
+    data = enc.finish()
+    t2 = time.time()
+    dec = orc.Decoder(data)
+    out = dec.decode(tab, 8, None, nsym)
+    dec.close()
+    t3 = time.time()
+    assert np.array_equal(out.astype(np.int32), sym)
     return {"value": px / dt / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "coder_single_thread_Msym_per_s": {"encode": nsym / (t2 - t1) / 1e6, "decode": nsym / (t3 - t2) / 1e6},
             "sample": "oracle enc+dec of %d latent crops of %dx%d (=%d px of 512x1024 ERPs), full 12-layer x3 model, %.1f s" % (reps, ch, cw, int(px), dt)}
 
 
