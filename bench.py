@@ -38,6 +38,7 @@ PIXELS = 512 * 1024
 MODEL_IDX, SSIM = 3, 1
 # algorithmic work per image, exact counts from the mask rule (SURVEY.md §8d / BASELINE.md §3)
 HIDDEN_GMAC = 11.23                     # one hidden layer, 3 stacked nets
+NET_GMAC = 123.42                       # the whole 12-layer x 3-net latent entropy model, one direction
 F32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 MFMA dense peak
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
@@ -248,6 +249,10 @@ def main():
                          "hbm": {"algorithmic_bytes_per_launch": bytes_per_launch, "achieved": achieved, "isolated": iso_gbs,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "frac_isolated": iso_gbs / HBM_PEAK_GBS},
+                         "aggregate": {"achieved": 2 * 2 * NET_GMAC * 1e9 * B / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
+                                       "frac": 2 * 2 * NET_GMAC * 1e9 * B / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                       "note": "algorithmic FLOPs of every conv layer of encode + decode of the step / wall time of the step "
+                                               "(all streams; includes the arithmetic-coder phases that are not hidden)"},
                          "ec_hidden_ms_per_step": ec_t / args.steps, "dc_hidden_ms_per_step": dc_t / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
