@@ -80,7 +80,8 @@ def test_cast_entropy_parameter():
 @pytest.mark.parametrize("G,H,W,B,seed", [(6, 8, 12, 3, 11), (8, 6, 10, 1, 12), (48, 8, 16, 2, 13),
                                           (4, 64, 12, 1, 16),      # full-height anti-diagonals: every lane of the wave is an image row
                                           (5, 66, 10, 2, 14),      # H > 64: row-major encode kernel + LDS-DMA decode kernel
-                                          (4, 64, 6, 1, 15)])      # W < 7: row-major encode kernel, diagonal decode kernel
+                                          (4, 64, 6, 1, 15),       # W < 7: row-major encode kernel, diagonal decode kernel
+                                          (3, 66, 68, 1, 17)])     # H, W > 64 (the 1024x2048 regime): generic 16x16x4 kernels
 def test_fused_codec_matches_oracle(G, H, W, B, seed):
     """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode."""
     from lic360_fused import FusedCodec
