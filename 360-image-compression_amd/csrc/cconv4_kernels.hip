@@ -271,11 +271,10 @@ LIC360_API int lic360_cconv4_ec(void *stream, const lic360_conv_plan *p, const f
 LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
     ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
-    ARG_CHECK(h <= 64 || w <= 64);                                      // an anti-diagonal must fit one wave (64 positions)
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
     {
         const char *v = getenv("LIC360_DC4");                           // "3" selects the LDS-DMA kernel (A/B runs)
-        if (h > 64 || (v && v[0] == '3')) return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
+        if (v && v[0] == '3' && (h <= 64 || w <= 64)) return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
     }
     return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
 }
@@ -296,13 +295,13 @@ LIC360_API int lic360_ec4_layout(int h, int w, int *hp, int *wp) {
 // wrapped diagonal sg = (th + tw + 2) % wpp at [(sg + row0) * pitch + th + 2]; diagonals < rows - wpp - row0 are stored a
 // second time wpp rows further down and diagonals >= wpp - row0 a second time wpp rows further up.
 LIC360_API int lic360_ec6_layout(int h, int w, int *rows, int *pitch, int *row0, int *wpp) {
-    ARG_CHECK(h > 0 && h <= 64 && w >= 7 && rows && pitch && row0 && wpp);             // the 11-row band must not overlap itself
+    ARG_CHECK(h > 0 && w >= 7 && rows && pitch && row0 && wpp);                        // the 11-row band must not overlap itself
     *rows = E6_ROWS(w); *pitch = D3_HP(h); *row0 = E6_R0; *wpp = E6_WPP(w);
     return 0;
 }
 LIC360_API int lic360_cconv4_ec_diag(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                      const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod) {
-    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && h > 0 && h <= 64 && w >= 7 && x_mod > 0);
+    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && h > 0 && w >= 7 && x_mod > 0);
     return launch_cconv4v6_ec((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, x_mod);
 }
 LIC360_API int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,

@@ -326,7 +326,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     if (rc) return 1;
     const char *force = getenv("LIC360_FUSED_CONV");                  // "16" forces the 16x16x4 kernels (A/B comparisons)
     c->use4 = lic360_conv4_supported(c->plan[0]) && lic360_conv4_supported(c->plan[1]) && lic360_conv4_supported(c->plan[2]) &&
-              (h <= 64 || w <= 64) && !(force && force[0] == '1' && force[1] == '6');
+              !(force && force[0] == '1' && force[1] == '6');
     c->h_idx.resize(2 * (size_t)c->HW);
     c->h_pidx.resize(h + w);
     lic360_code_contex(h, w, c->h_idx.data(), c->h_pidx.data());
@@ -351,7 +351,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     else { c->sk_rows = c->S; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
     const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = 4096;   // TAIL: band fetches may run past the last row
     const char *force_ec = getenv("LIC360_EC4");                       // "3" keeps the row-major LDS-DMA encode kernel (A/B runs)
-    if (c->use4 && h <= 64 && w >= 7 && !(force_ec && force_ec[0] == '3')) {
+    if (c->use4 && w >= 7 && !(force_ec && force_ec[0] == '3')) {
         if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
     } else if (c->use4) { if (lic360_ec4_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else { c->e_hp = h; c->e_wp = w; c->e_off = 0; }

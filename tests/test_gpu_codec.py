@@ -79,9 +79,10 @@ def test_cast_entropy_parameter():
 
 @pytest.mark.parametrize("G,H,W,B,seed", [(6, 8, 12, 3, 11), (8, 6, 10, 1, 12), (48, 8, 16, 2, 13),
                                           (4, 64, 12, 1, 16),      # full-height anti-diagonals: every lane of the wave is an image row
-                                          (5, 66, 10, 2, 14),      # H > 64: row-major encode kernel + LDS-DMA decode kernel
+                                          (5, 66, 10, 2, 14),      # H > 64: two row segments per diagonal
+                                          (3, 130, 8, 1, 18),      # three row segments, the last one 6 rows
                                           (4, 64, 6, 1, 15),       # W < 7: row-major encode kernel, diagonal decode kernel
-                                          (3, 66, 68, 1, 17)])     # H, W > 64 (the 1024x2048 regime): generic 16x16x4 kernels
+                                          (3, 66, 68, 1, 17)])     # H, W > 64 (the 1024x2048 regime)
 def test_fused_codec_matches_oracle(G, H, W, B, seed):
     """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode."""
     from lic360_fused import FusedCodec
@@ -101,3 +102,26 @@ def test_fused_codec_matches_oracle(G, H, W, B, seed):
         assert streams[1] == b"\x80"
     out = fc.decode(streams, dev(mask)).cpu().numpy()
     assert np.array_equal(out, code * mask)
+
+
+@pytest.mark.parametrize("G,H,W,B,seed", [(6, 8, 12, 2, 21), (4, 66, 10, 1, 22)])
+def test_fused_codec_previous_generation_kernels(monkeypatch, G, H, W, B, seed):
+    """The LDS-DMA / row-major conv kernels kept as A/B references (LIC360_DC4=3, LIC360_EC4=3) and the generic 16x16x4
+    kernels (LIC360_FUSED_CONV=16) produce the same bitstreams."""
+    from lic360_fused import FusedCodec
+    rng = np.random.default_rng(seed)
+    layers = rc.make_main_params(2000 + seed, G)
+    items = [latent(rng, G, H, W) for _ in range(B)]
+    code = np.concatenate([it[0] for it in items], 0)
+    mask = np.concatenate([it[1] for it in items], 0)
+    ref = [rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G) for i in range(B)]
+    for env in ({"LIC360_DC4": "3", "LIC360_EC4": "3"}, {"LIC360_FUSED_CONV": "16"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fc = FusedCodec(G, H, W, max_batch=B)
+        fc.load_layers(layers)
+        streams = fc.encode(dev(code), dev(mask))
+        assert streams == ref, env
+        assert np.array_equal(fc.decode(streams, dev(mask)).cpu().numpy(), code * mask), env
+        for k in env:
+            monkeypatch.delenv(k)

@@ -361,7 +361,8 @@ def _to_ec6(x, maps):
 
 
 @pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 7, 70), (6, 4, 4, True, True, 3, 3, 5, 66), (48, 4, 4, True, True, 3, 3, 3, 64),
-                                  (48, 4, 3, True, False, 3, 6, 4, 20), (9, 4, 4, True, True, 1, 2, 64, 9), (7, 1, 4, False, False, 1, 1, 33, 40)],
+                                  (48, 4, 3, True, False, 3, 6, 4, 20), (9, 4, 4, True, True, 1, 2, 64, 9), (7, 1, 4, False, False, 1, 1, 33, 40),
+                                  (5, 4, 4, True, True, 1, 1, 70, 9), (4, 4, 3, True, False, 1, 2, 130, 8), (4, 1, 4, False, True, 1, 1, 123, 7)],
                          ids=lambda c: "g%d_%dto%d_%dx%d" % (c[0], c[1], c[2], c[7], c[8]))
 def test_cconv4_ec_diag_bit_exact(lic, case):
     """encode-order conv on the wrapped diagonal-major layout (lic360_cconv4_ec_diag) == oracle, incl. the duplicated rows"""
