@@ -493,6 +493,225 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ importance-map stream
+// Device-resident counterpart of ImpEntEncoderFast / ImpEntDecoder (test/lic360_demo.py:143-189, 241-290): one group, a
+// 12-layer spatially causal net with `cpg` hidden channels, an nsym-way softmax table per position
+// (entropy_table_cuda.cu:24-96), symbols = importance levels, input scale 2/(nsym-2) and bias -1.  The convolutions run on
+// the generic 16x16x4 kernels (cin = cpg is outside the leaf-resident kernel's shapes); tables and the coder on the GPU.
+struct lic360_impcodec {
+    int H, W, HW, P, cpg, nsym, maxB;
+    float sc;
+    lic360_conv_plan *plan[3];
+    float *packed[12], *bias[12], *act[12];
+    bool layer_set[12];
+    std::vector<int> h_idx, h_pidx;
+    int *d_idx, *d_pidx;
+    float *e_x0, *e_buf[3];
+    uint2 *e_rec;
+    float *d_x0, *d_act[11], *d_y;
+    int *d_tab;                                 // [maxB][tab_pitch][IMP_TW] tables of the current plane
+    int tab_pitch;
+    AcDevState *d_state;
+};
+#define IMP_TW 64                              // ints per table row (nsym + 1 <= 64), one per lane
+
+__global__ void k_imp_prep(const float *__restrict__ lv, float *__restrict__ x0, long total, float sc) {
+    GRID_STRIDE(i, total) x0[i] = lic360_affine(lv[i], sc, -1.0f);                 // Scale(-1, 2/47): lic360_demo.py:168
+}
+// nsym-way softmax CDF of one position (entropy_table_cuda.cu:24-96)
+__device__ __forceinline__ void imp_table(const float *__restrict__ y, long base, long cstride, int nsym, float *T) {
+    float tmp[64], lg[64];
+    for (int i = 0; i < nsym; ++i) lg[i] = y[base + i * cstride];
+    lic360_softmax_cdf(lg, T, tmp, nsym, 65536.0f);
+    lic360_cdf_fixup(T, nsym, 1);
+}
+__global__ void k_imp_enc_tables(const float *__restrict__ y, const float *__restrict__ lv, const int *__restrict__ pidx, uint2 *__restrict__ rec,
+                                 int B, int H, int W, int nsym) {
+    const long HW = (long)H * W, total = HW * B;
+    GRID_STRIDE(i, total) {
+        const int tw = (int)(i % W), th = (int)((i / W) % H), b = (int)(i / HW), s = th + tw;
+        float T[65];
+        imp_table(y, (long)b * nsym * HW + (long)th * W + tw, HW, nsym, T);
+        int sym = (int)lv[i];
+        sym = sym < 0 ? 0 : (sym > nsym - 1 ? nsym - 1 : sym);
+        rec[(long)b * HW + pidx[s] + (th - (s >= W ? s - W + 1 : 0))] = make_uint2((unsigned)(int)T[sym], (unsigned)(int)T[sym + 1]);
+    }
+}
+__global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__ y, const int *__restrict__ idx, int start, int len,
+                                                       int *__restrict__ tab, int tab_pitch, int H, int W, int nsym) {
+    const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= len) return;
+    const long HW = (long)H * W;
+    const int th = idx[start + i], tw = idx[start + i + HW];
+    float T[65];
+    imp_table(y, (long)b * nsym * HW + (long)th * W + tw, HW, nsym, T);
+    int *row = tab + ((long)b * tab_pitch + i) * IMP_TW;
+    for (int k = 0; k <= nsym; ++k) row[k] = (int)T[k];
+}
+// one wave per image: lane k holds T[k] of the current symbol; the symbol is the number of inner entries <= target
+__global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ tab, int tab_pitch, const int *__restrict__ idx, int start, int len,
+                                                      AcDevState *__restrict__ state, const uint8_t *__restrict__ bytes, long cap,
+                                                      const int *__restrict__ nbytes, float *__restrict__ x0, float *__restrict__ out,
+                                                      int H, int W, int nsym, float sc) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const long HW = (long)H * W;
+    AcDevState ds = state[b];
+    AcState st;
+    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = ds.error;
+    DevBits rd;
+    rd.buf = bytes + (long)b * cap; rd.len = nbytes[b]; rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
+    rd.fetch_window();
+    const int *rows = tab + (long)b * tab_pitch * IMP_TW;
+    int tnext = len > 0 ? rows[lane] : 0;
+    for (int j = 0; j < len; ++j) {
+        const int tl = tnext;
+        if (j + 1 < len) tnext = rows[(long)(j + 1) * IMP_TW + lane];               // next row is in flight while this symbol decodes
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(tl, nsym);
+        const uint32_t target = ac_decode_target(st, total);
+        const int sym = __popcll(__ballot(lane >= 1 && lane < nsym && target >= (uint32_t)tl));
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(tl, sym), hi = (uint32_t)__builtin_amdgcn_readlane(tl, sym + 1);
+        ac_decode_consume_from(st, rd, lo, hi, total);
+        if (lane == 0) {
+            const int th = idx[start + j], tw = idx[start + j + HW];
+            const long o = (long)b * HW + (long)th * W + tw;
+            x0[o] = lic360_affine((float)sym, sc, -1.0f);                           // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
+            out[o] = (float)sym;
+        }
+    }
+    if (lane == 0) {
+        ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error = st.error;
+        ds.pos = rd.pos; ds.acc = rd.acc; ds.nacc = rd.nacc;
+        state[b] = ds;
+    }
+}
+
+LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsym, int max_batch, lic360_impcodec **out) {
+    ARG_CHECK(out && h > 0 && w > 0 && h < 4096 && w < 4096 && hidden_channels > 0 && nsym >= 3 && nsym < IMP_TW && max_batch > 0);
+    lic360_impcodec *c = new lic360_impcodec();
+    memset(c->layer_set, 0, sizeof(c->layer_set));
+    c->H = h; c->W = w; c->HW = h * w; c->P = h + w - 1; c->cpg = hidden_channels; c->nsym = nsym; c->maxB = max_batch;
+    c->sc = 2.0f / (float)(nsym - 2);
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = nullptr;
+    int rc = 0;
+    rc |= lic360_conv_plan_create(1, 1, hidden_channels, 5, 5, &c->plan[0]);
+    rc |= lic360_conv_plan_create(hidden_channels, 1, hidden_channels, 5, 6, &c->plan[1]);
+    rc |= lic360_conv_plan_create(hidden_channels, 1, nsym, 5, 6, &c->plan[2]);
+    if (rc) return 1;
+    c->h_idx.resize(2 * (size_t)c->HW);
+    c->h_pidx.resize(h + w);
+    lic360_code_contex(h, w, c->h_idx.data(), c->h_pidx.data());
+    c->tab_pitch = ((h < w ? h : w) + 63) / 64 * 64;
+    const size_t B = max_batch, HW = c->HW, C = hidden_channels, CE = hidden_channels > nsym ? hidden_channels : nsym;   // the last layer writes nsym planes
+    rc |= dmalloc(&c->d_idx, c->h_idx.size());
+    rc |= dmalloc(&c->d_pidx, c->h_pidx.size());
+    rc |= dmalloc(&c->e_x0, B * HW);
+    for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], B * CE * HW);
+    rc |= dmalloc(&c->e_rec, B * HW);
+    rc |= dmalloc(&c->d_x0, B * HW);
+    for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], B * C * HW);
+    rc |= dmalloc(&c->d_y, B * (size_t)nsym * HW);
+    rc |= dmalloc(&c->d_tab, B * (size_t)c->tab_pitch * IMP_TW);
+    rc |= dmalloc(&c->d_state, B);
+    if (rc) return 1;
+    HIP_TRY(hipMemcpy(c->d_idx, c->h_idx.data(), c->h_idx.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_pidx, c->h_pidx.data(), c->h_pidx.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(c->d_x0, 0, B * HW * 4));
+    for (int i = 0; i < 11; ++i) HIP_TRY(hipMemset(c->d_act[i], 0, B * C * HW * 4));
+    HIP_TRY(hipMemset(c->d_y, 0, B * (size_t)nsym * HW * 4));
+    *out = c;
+    return 0;
+}
+LIC360_API void lic360_impcodec_destroy(lic360_impcodec *c) {
+    if (!c) return;
+    for (int i = 0; i < 3; ++i) lic360_conv_plan_destroy(c->plan[i]);
+    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); }
+    (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->e_x0);
+    for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
+    (void)hipFree(c->e_rec); (void)hipFree(c->d_x0);
+    for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
+    (void)hipFree(c->d_y); (void)hipFree(c->d_tab); (void)hipFree(c->d_state);
+    delete c;
+}
+LIC360_API int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int layer, const float *weight, const float *bias, const float *act) {
+    ARG_CHECK(c && layer >= 0 && layer < 12 && weight && bias);
+    ARG_CHECK((act != nullptr) == (layer != 11));
+    lic360_conv_plan *p = c->plan[plan_of(layer)];
+    if (!c->packed[layer]) {
+        if (dmalloc(&c->packed[layer], (size_t)lic360_conv_plan_packed_floats(p))) return 1;
+        if (dmalloc(&c->bias[layer], (size_t)p->nout)) return 1;
+        if (act && dmalloc(&c->act[layer], (size_t)p->nout)) return 1;
+    }
+    if (lic360_conv_pack(stream, p, weight, 1, c->packed[layer])) return 1;
+    HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->layer_set[layer] = true;
+    return 0;
+}
+static int imp_ready(const lic360_impcodec *c, int B) {
+    ARG_CHECK(c && B > 0 && B <= c->maxB);
+    for (int i = 0; i < 12; ++i)
+        if (!c->layer_set[i]) { lic360_set_error("importance codec layer %d has no weights (call lic360_impcodec_set_layer)", i); return 2; }
+    return 0;
+}
+LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const float *levels, int B, uint8_t *bytes, long cap, int *nbytes, int *err) {
+    if (imp_ready(c, B)) return 2;
+    ARG_CHECK(levels && bytes && nbytes && err && cap > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c->H, W = c->W;
+    const long total = (long)B * c->HW;
+    hipLaunchKernelGGL(k_imp_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, levels, c->e_x0, total, c->sc);
+    LAUNCH_CHECK();
+    float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
+    auto ec = [&](int layer, const float *xin, const float *res, float *dst) -> int {
+        return lic360_cconv_ec_ex(stream, c->plan[plan_of(layer)], xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, 1, B);
+    };
+    if (ec(0, c->e_x0, nullptr, cur)) return 1;
+    for (int blk = 0; blk < 5; ++blk) {
+        if (ec(1 + 2 * blk, cur, nullptr, t1)) return 1;
+        if (ec(2 + 2 * blk, t1, cur, nxt)) return 1;
+        float *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (ec(11, cur, nullptr, t1)) return 1;                                         // [B, nsym, H, W] (uses the first nsym planes of the buffer)
+    hipLaunchKernelGGL(k_imp_enc_tables, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, t1, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
+    LAUNCH_CHECK();
+    return 0;
+}
+LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
+                                      float *levels_out, int *err) {
+    if (imp_ready(c, B)) return 2;
+    ARG_CHECK(bytes && nbytes && levels_out && err && cap > 0 && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int H = c->H, W = c->W;
+    hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
+    LAUNCH_CHECK();
+    const int *pih = c->h_pidx.data();
+    auto dc = [&](int layer, const float *xin, const float *res, float *dst, int p) -> int {
+        return lic360_cconv_dc_plane_ex(stream, c->plan[plan_of(layer)], xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, 1,
+                                        c->d_idx, c->d_pidx, pih, p, B, 0);
+    };
+    for (int p = 0; p < c->P; ++p) {
+        if (dc(0, c->d_x0, nullptr, c->d_act[0], p)) return 1;
+        for (int blk = 0; blk < 5; ++blk) {
+            const int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
+            if (dc(a, c->d_act[a - 1], nullptr, c->d_act[a], p)) return 1;
+            if (dc(b2, c->d_act[a], c->d_act[a - 1], c->d_act[b2], p)) return 1;
+        }
+        if (dc(11, c->d_act[10], nullptr, c->d_y, p)) return 1;
+        const int start = pih[p], len = pih[p + 1] - pih[p];
+        if (len <= 0) continue;
+        hipLaunchKernelGGL(k_imp_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_imp_dec_plane, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
+                           c->d_x0, levels_out, H, W, c->nsym, c->sc);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ timing hooks
 LIC360_API int lic360_codec_profile_enable(lic360_codec *c, int on) {
     ARG_CHECK(c);

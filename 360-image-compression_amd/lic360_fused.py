@@ -122,3 +122,89 @@ class FusedCodec(object):
         nec, ndc = C.c_long(0), C.c_long(0)
         _chk(_lib.lic360_codec_profile_read(self._h, C.byref(ec), C.byref(nec), C.byref(dc), C.byref(ndc)))
         return dict(ec_ms=ec.value, ec_launches=nec.value, dc_ms=dc.value, dc_launches=ndc.value)
+
+
+class FusedImpCodec(object):
+    """Device-resident importance-map stream: ImpEntEncoderFast + ImpEntDecoder (test/lic360_demo.py:143-189, 241-290) for a
+    batch of maps.  levels: float32 [b,1,h,w] with values in {0..nsym-1}; bitstreams == the reference's `<code>_imp` files."""
+
+    def __init__(self, h, w, max_batch, hidden_channels=144, nsym=49, device=0, cap_bytes=None):
+        self.H, self.W, self.maxB, self.device = int(h), int(w), int(max_batch), int(device)
+        self.cpg, self.nsym = int(hidden_channels), int(nsym)
+        self.cap = int(cap_bytes) if cap_bytes else max(4096, 2 * self.H * self.W)
+        self.cap = (self.cap + 3) // 4 * 4
+        self._h = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            _chk(_lib.lic360_impcodec_create(self.H, self.W, self.cpg, self.nsym, self.maxB, C.byref(self._h)))
+        dev = "cuda:%d" % self.device
+        self.bytes = torch.zeros((self.maxB, self.cap), dtype=torch.uint8, device=dev)
+        self.nbytes = torch.zeros((self.maxB,), dtype=torch.int32, device=dev)
+        self.err = torch.zeros((self.maxB,), dtype=torch.int32, device=dev)
+        self.levels_out = torch.zeros((self.maxB, 1, self.H, self.W), dtype=torch.float32, device=dev)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lic360_impcodec_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def load_layers(self, layers):
+        """layers: 12 dicts with numpy/torch 'w' [nout,C,5,5], 'b' [nout], 'a' [nout] or None."""
+        dev = "cuda:%d" % self.device
+        to = lambda a: None if a is None else torch.as_tensor(a).to(dev).contiguous()
+        keep = []
+        for i, l in enumerate(layers):
+            w, b, a = to(l["w"]), to(l["b"]), to(l["a"])
+            keep.append((w, b, a))
+            _chk(_lib.lic360_impcodec_set_layer(_stream(self.device), self._h, i, _p(w), _p(b), _p(a)))
+        torch.cuda.synchronize(self.device)
+
+    def load_from_driver(self, drv):
+        """drv: an ImpEntEncoderFast / ImpEntDecoder whose net.* parameters were filled by cast_imp_entropy_parameter."""
+        mods = [drv.net[0]]
+        for i in range(1, 6):
+            mods += [drv.net[i].conv1, drv.net[i].conv2]
+        mods.append(drv.net[6])
+        self.load_layers([dict(w=m.weight.data, b=m.bias.data, a=None if m.relu is None else m.relu.data) for m in mods])
+
+    def _check(self, t):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape[1:]) == (1, self.H, self.W) and 0 < t.shape[0] <= self.maxB):
+            raise Lic360Error("levels must be a contiguous float32 device tensor [b<=%d,1,%d,%d]" % (self.maxB, self.H, self.W))
+
+    def encode_async(self, levels):
+        self._check(levels)
+        b = levels.shape[0]
+        _chk(_lib.lic360_impcodec_encode(_stream(self.device), self._h, _p(levels), b, _p(self.bytes), C.c_long(self.cap), _p(self.nbytes), _p(self.err)))
+        return b
+
+    def decode_async(self, b):
+        _chk(_lib.lic360_impcodec_decode(_stream(self.device), self._h, _p(self.bytes), C.c_long(self.cap), _p(self.nbytes), int(b),
+                                         _p(self.levels_out), _p(self.err)))
+        return self.levels_out[:b]
+
+    def encode(self, levels):
+        b = self.encode_async(levels)
+        nb = self.nbytes[:b].cpu().tolist()
+        er = self.err[:b].cpu().tolist()
+        if any(er):
+            raise Lic360Error("arithmetic encoder fault / capacity overflow: %s" % er)
+        host = self.bytes[:b].cpu()
+        return [bytes(host[i, :nb[i]].numpy().tobytes()) for i in range(b)]
+
+    def decode(self, streams):
+        b = len(streams)
+        host = torch.zeros((self.maxB, self.cap), dtype=torch.uint8)
+        nb = torch.zeros((self.maxB,), dtype=torch.int32)
+        for i, s in enumerate(streams):
+            if len(s) > self.cap:
+                raise Lic360Error("bitstream %d longer than the codec capacity" % i)
+            host[i, :len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8)
+            nb[i] = len(s)
+        self.bytes.copy_(host)
+        self.nbytes.copy_(nb)
+        out = self.decode_async(b).clone()
+        if int(self.err[:b].abs().sum().item()):
+            raise Lic360Error("arithmetic decoder fault (corrupt stream?): %s" % self.err[:b].cpu().tolist())
+        return out

@@ -186,6 +186,17 @@ int lic360_codec_encode(void *stream, lic360_codec *codec, const float *code, co
 int lic360_codec_decode(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
                         const float *mask, int b, float *code_out, int *err);
 
+/* Device-resident importance-map stream (ImpEntEncoderFast / ImpEntDecoder, test/lic360_demo.py:143-189, 241-290): one
+ * group, 12 spatially causal layers with `hidden_channels` channels, nsym-way softmax tables (entropy_table_cuda.cu:24-96),
+ * symbols = importance levels.  levels / levels_out: float [B,1,h,w]; weights per layer as [nout][C][5][5] (one net).
+ * Bitstream buffers as in lic360_codec_encode / _decode. */
+typedef struct lic360_impcodec lic360_impcodec;
+int lic360_impcodec_create(int h, int w, int hidden_channels, int nsym, int max_batch, lic360_impcodec **out);
+void lic360_impcodec_destroy(lic360_impcodec *c);
+int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int layer, const float *weight, const float *bias, const float *act);
+int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const float *levels, int B, uint8_t *bytes, long cap, int *nbytes, int *err);
+int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B, float *levels_out, int *err);
+
 /* timing hooks for bench.py: HIP events around every hidden-layer conv launch (encode-order / decode-order),
  * recorded on the caller's stream; read() returns the summed elapsed ms + launch counts and resets */
 int lic360_codec_profile_enable(lic360_codec *codec, int on);

@@ -125,3 +125,20 @@ def test_fused_codec_previous_generation_kernels(monkeypatch, G, H, W, B, seed):
         assert np.array_equal(fc.decode(streams, dev(mask)).cpu().numpy(), code * mask), env
         for k in env:
             monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("cpg,nsym,H,W,B,seed", [(8, 49, 8, 12, 3, 31), (144, 49, 4, 6, 1, 32), (16, 10, 32, 10, 2, 33)])
+def test_fused_importance_codec_matches_oracle(cpg, nsym, H, W, B, seed):
+    """Device-resident importance-map stream: byte-identical to the oracle's ImpEntEncoderFast pipeline, exact decode."""
+    from lic360_fused import FusedImpCodec
+    rng = np.random.default_rng(seed)
+    layers = rc.make_imp_params(4000 + seed, cpg, nsym)
+    levels = rng.integers(0, nsym, (B, 1, H, W)).astype(np.float32)
+    fc = FusedImpCodec(H, W, max_batch=4, hidden_channels=cpg, nsym=nsym)
+    fc.load_layers(layers)
+    streams = fc.encode(dev(levels))
+    for i in range(B):
+        assert streams[i] == rc.encode_imp(levels[i:i + 1], layers, nsym), "image %d" % i
+    out = fc.decode(streams).cpu().numpy()
+    assert np.array_equal(out, levels)
+    assert np.array_equal(rc.decode_imp(streams[0], layers, H, W, nsym), levels[0:1])
