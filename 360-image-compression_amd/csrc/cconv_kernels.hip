@@ -203,13 +203,18 @@ LIC360_API int lic360_cconv_ec_ex(void *stream, const lic360_conv_plan *p, const
 // DC kernel: grid = (chunks of 16 positions, n_mtiles, N), block = one wave.
 // Positions of output tile mi on plane psum: diagonals s = psum - g, g in [glo, ghi] -> contiguous
 // range of the scan order.  Only rows whose group equals psum - th - tw are stored.
-__global__ __launch_bounds__(64) void k_cconv_dc(
+// Decode order: 8 waves per (output tile, 16 plane positions) task.  Wave w evaluates the leaves r = 16w .. 16w+15 of the
+// visiting order -- a complete sub-tree of the reference's reduction -- so the serial K chain (operands gathered from
+// global memory, one step prefetched) is 8x shorter than with one wave per task; the three top levels of the binary-counter
+// merge are then applied to the 8 partial tiles in the same operand order ((B0+B1)+(B2+B3))+((B4+B5)+(B6+B7)).
+__global__ __launch_bounds__(512) void k_cconv_dc(
     const float *__restrict__ x, const float *__restrict__ packed, const float *__restrict__ bias, const float *__restrict__ act,
     float *__restrict__ out, const int *__restrict__ mt_rec_start, const int *__restrict__ leaf_cnt, const int *__restrict__ term,
     const int *__restrict__ mt_glo, const int *__restrict__ mt_ghi, const int *__restrict__ idx, const int *__restrict__ plane_idx,
     int C, int H, int W, int nout, int cout, int half, int npb, long packed_per_net, int psum,
     const float *__restrict__ residual, int x_mod, long x_cs, long x_hs, long x_ws, long o_cs, long o_hs, long o_ws) {
-    const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
+    __shared__ f32x4 part[8][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), kq = lane >> 4, col = lane & 15;
     const int mi = blockIdx.y, n = blockIdx.z, nbatch = n / npb;
     // diagonal range of this tile on this plane
     int s_lo = psum - mt_ghi[mi], s_hi = psum - mt_glo[mi];
@@ -223,39 +228,53 @@ __global__ __launch_bounds__(64) void k_cconv_dc(
     const int th = live ? idx[q] : 0, tw = live ? idx[q + H * W] : 0;
     const float *xn = x + (long)(n % x_mod) * C * x_cs;
     const float *wp = packed + (long)nbatch * packed_per_net;
-    long rec = mt_rec_start[mi];
     const int *cnt = leaf_cnt + mi * 128;
-    TREE_DECL(1);
+    // first record of this wave's 16 leaves
+    int before = 0;
+    for (int i = lane; i < 16 * wv; i += 64) before += cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    long rec = mt_rec_start[mi] + before;
+    f32x4 cur[1], s0[1], s1[1], s2[1], s3[1];
 #define DC_LOADB(T, dst)                                                            \
     {                                                                               \
         int ph = th + ((T >> 16) & 0xff) - half, pw = tw + ((T >> 24) & 0xff) - half; \
         dst = 0.0f;                                                                 \
         if (live && ph >= 0 && ph < H && pw >= 0 && pw < W) dst = xn[(long)(T & 0xffff) * x_cs + ph * x_hs + pw * x_ws]; \
     }
-    float a_cur = wp[rec * 64 + lane], b_cur;
-    int t_cur = term[rec * 4 + kq];
-    DC_LOADB(t_cur, b_cur);
-    for (int r = 0; r < 128; ++r) {
-        const int nk = cnt[r];
+    // operands of records rec .. rec+3 in flight (LIC360_REC_PAD = 4 records are readable past the end)
+    float a0 = wp[rec * 64 + lane], a1 = wp[(rec + 1) * 64 + lane], a2 = wp[(rec + 2) * 64 + lane], b0, b1, b2;
+    {
+        const int t0 = term[rec * 4 + kq], t1 = term[(rec + 1) * 4 + kq], t2 = term[(rec + 2) * 4 + kq];
+        DC_LOADB(t0, b0);
+        DC_LOADB(t1, b1);
+        DC_LOADB(t2, b2);
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = rr, nk = cnt[16 * wv + rr];
         cur[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < nk; ++s) {
-            float a_nxt = wp[(rec + 1) * 64 + lane], b_nxt;
-            int t_nxt = term[(rec + 1) * 4 + kq];
-            DC_LOADB(t_nxt, b_nxt);
-            cur[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur, cur[0], 0, 0, 0);
-            a_cur = a_nxt; b_cur = b_nxt; t_cur = t_nxt; ++rec;
+            const float a3 = wp[(rec + 3) * 64 + lane];
+            float b3;
+            const int t3 = term[(rec + 3) * 4 + kq];
+            DC_LOADB(t3, b3);
+            cur[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, cur[0], 0, 0, 0);
+            a0 = a1; a1 = a2; a2 = a3; b0 = b1; b1 = b2; b2 = b3; ++rec;
         }
-        TREE_MERGE(1);
+        do { TREE_LEVEL(1, 0, s0) TREE_LEVEL(1, 1, s1) TREE_LEVEL(1, 2, s2) TREE_LEVEL(1, 3, s3) } while (0);
     }
 #undef DC_LOADB
-    if (!live) return;
+    part[wv][lane] = cur[0];
+    __syncthreads();
+    if (wv != 0 || !live) return;
+    const f32x4 tot = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
     const int g = psum - th - tw;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         int o = mi * 16 + kq * 4 + reg;
         if (o < nout && o / cout == g) {
             int bid = nbatch * nout + o;
-            float sv = cur[0][reg] + bias[bid];
+            float sv = tot[reg] + bias[bid];
             if (act) { if (sv < 0) sv = sv * act[bid]; }            // cconv_dc_cuda.cu:360-362
             const long oi = ((long)n * nout + o) * o_cs + th * o_hs + tw * o_ws;
             if (residual) sv = sv + residual[oi];                   // fused TileAdd (tile_add_cuda.cu:35)
@@ -292,7 +311,7 @@ LIC360_API int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *p,
     }
     if (maxpos == 0) return 0;
     dim3 grid((maxpos + 15) / 16, p->n_mtiles, n);
-    hipLaunchKernelGGL(k_cconv_dc, grid, dim3(64), 0, (hipStream_t)stream, x, packed, bias, act, out, p->d_mt_rec_start, p->d_leaf_cnt,
+    hipLaunchKernelGGL(k_cconv_dc, grid, dim3(512), 0, (hipStream_t)stream, x, packed, bias, act, out, p->d_mt_rec_start, p->d_leaf_cnt,
                        p->d_term, p->d_mt_glo, p->d_mt_ghi, idx_dev, plane_idx_dev, p->C, h, w, p->nout, p->cout, p->half, n / nb,
                        lic360_conv_plan_packed_floats(p), psum, residual, x_mod, cs, hs, ws, cs, hs, ws);
     LAUNCH_CHECK();

@@ -537,14 +537,16 @@ __global__ void k_imp_enc_tables(const float *__restrict__ y, const float *__res
         rec[(long)b * HW + pidx[s] + (th - (s >= W ? s - W + 1 : 0))] = make_uint2((unsigned)(int)T[sym], (unsigned)(int)T[sym + 1]);
     }
 }
+// decode activations are diagonal-major [n][c][H+W-1][H] (cell (th, tw) at (th+tw)*H + th): the 16 plane positions a
+// conv wave gathers are contiguous
 __global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__ y, const int *__restrict__ idx, int start, int len,
                                                        int *__restrict__ tab, int tab_pitch, int H, int W, int nsym) {
     const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
     if (i >= len) return;
-    const long HW = (long)H * W;
+    const long HW = (long)H * W, SK = (long)(H + W - 1) * H;
     const int th = idx[start + i], tw = idx[start + i + HW];
     float T[65];
-    imp_table(y, (long)b * nsym * HW + (long)th * W + tw, HW, nsym, T);
+    imp_table(y, (long)b * nsym * SK + (long)(th + tw) * H + th, SK, nsym, T);
     int *row = tab + ((long)b * tab_pitch + i) * IMP_TW;
     for (int k = 0; k <= nsym; ++k) row[k] = (int)T[k];
 }
@@ -573,9 +575,8 @@ __global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ ta
         ac_decode_consume_from(st, rd, lo, hi, total);
         if (lane == 0) {
             const int th = idx[start + j], tw = idx[start + j + HW];
-            const long o = (long)b * HW + (long)th * W + tw;
-            x0[o] = lic360_affine((float)sym, sc, -1.0f);                           // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
-            out[o] = (float)sym;
+            x0[(long)b * (H + W - 1) * H + (long)(th + tw) * H + th] = lic360_affine((float)sym, sc, -1.0f);   // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
+            out[(long)b * HW + (long)th * W + tw] = (float)sym;
         }
     }
     if (lane == 0) {
@@ -607,17 +608,18 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
     rc |= dmalloc(&c->e_x0, B * HW);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], B * CE * HW);
     rc |= dmalloc(&c->e_rec, B * HW);
-    rc |= dmalloc(&c->d_x0, B * HW);
-    for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], B * C * HW);
-    rc |= dmalloc(&c->d_y, B * (size_t)nsym * HW);
+    const size_t SK = (size_t)(h + w - 1) * h;                            // diagonal-major decode planes
+    rc |= dmalloc(&c->d_x0, B * SK);
+    for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], B * C * SK);
+    rc |= dmalloc(&c->d_y, B * (size_t)nsym * SK);
     rc |= dmalloc(&c->d_tab, B * (size_t)c->tab_pitch * IMP_TW);
     rc |= dmalloc(&c->d_state, B);
     if (rc) return 1;
     HIP_TRY(hipMemcpy(c->d_idx, c->h_idx.data(), c->h_idx.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_pidx, c->h_pidx.data(), c->h_pidx.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(c->d_x0, 0, B * HW * 4));
-    for (int i = 0; i < 11; ++i) HIP_TRY(hipMemset(c->d_act[i], 0, B * C * HW * 4));
-    HIP_TRY(hipMemset(c->d_y, 0, B * (size_t)nsym * HW * 4));
+    HIP_TRY(hipMemset(c->d_x0, 0, B * SK * 4));
+    for (int i = 0; i < 11; ++i) HIP_TRY(hipMemset(c->d_act[i], 0, B * C * SK * 4));
+    HIP_TRY(hipMemset(c->d_y, 0, B * (size_t)nsym * SK * 4));
     *out = c;
     return 0;
 }
@@ -689,7 +691,7 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
     const int *pih = c->h_pidx.data();
     auto dc = [&](int layer, const float *xin, const float *res, float *dst, int p) -> int {
         return lic360_cconv_dc_plane_ex(stream, c->plan[plan_of(layer)], xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, 1,
-                                        c->d_idx, c->d_pidx, pih, p, B, 0);
+                                        c->d_idx, c->d_pidx, pih, p, B, 1);
     };
     for (int p = 0; p < c->P; ++p) {
         if (dc(0, c->d_x0, nullptr, c->d_act[0], p)) return 1;
