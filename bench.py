@@ -82,12 +82,13 @@ def ec_hidden_bytes_per_launch(b):
 
 def synth_latents(batch, seed0):
     from util import latent
-    codes, masks = [], []
+    codes, masks, levels = [], [], []
     for i in range(batch):
-        c, m, _ = latent(np.random.default_rng(seed0 + i), G, H, W)
+        c, m, lv = latent(np.random.default_rng(seed0 + i), G, H, W)
         codes.append(c)
         masks.append(m)
-    return np.concatenate(codes, 0), np.concatenate(masks, 0)
+        levels.append(lv)
+    return np.concatenate(codes, 0), np.concatenate(masks, 0), np.concatenate(levels, 0)
 
 
 def cpu_baseline(layers):
@@ -136,6 +137,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
                     "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-importance-pass", action="store_true", help="skip the extra (untimed for `value`) pass that also codes the importance maps")
     args = ap.parse_args()
 
     import lic360_shard as shard
@@ -151,7 +153,7 @@ def main():
     B = args.batch
     ns = max(1, min(args.streams, B))
     sizes = [B // ns + (1 if i < B % ns else 0) for i in range(ns)]
-    code_np, mask_np = synth_latents(B, seed0=1000 * rank)
+    code_np, mask_np, level_np = synth_latents(B, seed0=1000 * rank)
     codecs, codes, masks, streams = [], [], [], []
     o = 0
     for sz in sizes:
@@ -200,6 +202,37 @@ def main():
     torch.cuda.synchronize(dev)
     iso = codecs[0].profile_read()
     codecs[0].profile(False)
+    # extra pass, reported next to `value`: the same steps with the images' importance-map streams (32x64 maps, 49 levels,
+    # device-resident FusedImpCodec on the same streams) encoded and decoded as well -- both bitstreams of every image
+    with_imp = None
+    if not args.no_importance_pass:
+        from lic360_fused import FusedImpCodec
+        imp_layers = rc.make_imp_params(1000 * SSIM + MODEL_IDX)
+        icodecs, levels, o = [], [], 0
+        for sz in sizes:
+            ic = FusedImpCodec(H // 2, W // 2, max_batch=sz, device=local)
+            ic.load_layers(imp_layers)
+            icodecs.append(ic)
+            levels.append(torch.from_numpy(level_np[o:o + sz]).to(dev))
+            o += sz
+
+        def step_full():
+            for c, ic, cd, mk, lv, st in zip(codecs, icodecs, codes, masks, levels, streams):
+                with torch.cuda.stream(st):
+                    ic.encode_async(lv)
+                    c.encode_async(cd, mk)
+            for c, ic, cd, mk, lv, st in zip(codecs, icodecs, codes, masks, levels, streams):
+                with torch.cuda.stream(st):
+                    ic.decode_async(lv.shape[0])
+                    c.decode_async(mk, cd.shape[0])
+
+        step_full()
+        dt_full = shard.timed(step_full, args.steps, dev)
+        ok_imp = all(bool(torch.equal(ic.levels_out[:lv.shape[0]], lv)) and int(ic.err[:lv.shape[0]].abs().sum().item()) == 0
+                     for ic, lv in zip(icodecs, levels))
+        with_imp = {"value": world * B * args.steps * PIXELS / dt_full / 1e6, "unit": "Mpixel/s", "ms_per_step": dt_full / args.steps * 1e3,
+                    "roundtrip_exact": shard.all_ok(ok_imp and roundtrip_ok(), dev),
+                    "mean_importance_bytes": float(np.mean([float(ic.nbytes[:lv.shape[0]].float().mean().item()) for ic, lv in zip(icodecs, levels)]))}
     ok = shard.all_ok(ok, dev)
 
     if rank == 0:
@@ -238,7 +271,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic 512x1024 ERP latents per GPU (48x64x128 symbols + importance mask), "
                                    "model-idx 3 --ssim seeded weights, latent entropy encode+decode (BASELINE.json configs[3] per-GPU share)" % B,
-                       "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean())},
+                       "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean()),
+                       "with_importance_stream": with_imp},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "algorithmic_flops_per_launch": flops_per_launch, "images_per_launch": b0,
