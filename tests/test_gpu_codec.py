@@ -82,7 +82,9 @@ def test_cast_entropy_parameter():
                                           (5, 66, 10, 2, 14),      # H > 64: two row segments per diagonal
                                           (3, 130, 8, 1, 18),      # three row segments, the last one 6 rows
                                           (4, 64, 6, 1, 15),       # W < 7: row-major encode kernel, diagonal decode kernel
-                                          (3, 66, 68, 1, 17)])     # H, W > 64 (the 1024x2048 regime)
+                                          (3, 66, 68, 1, 17),      # H, W > 64 (the 1024x2048 regime)
+                                          (4, 64, 12, 16, 19),     # 16 images: short diagonals at both image corners carry two samples per wave
+                                          (6, 8, 12, 16, 20)])     # every diagonal short: all decode tasks carry two samples
 def test_fused_codec_matches_oracle(G, H, W, B, seed):
     """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode."""
     from lic360_fused import FusedCodec
@@ -93,7 +95,7 @@ def test_fused_codec_matches_oracle(G, H, W, B, seed):
     mask = np.concatenate([it[1] for it in items], 0)
     if B > 1:
         mask[1] = 0.0                      # one fully masked image -> bare terminator byte
-    fc = FusedCodec(G, H, W, max_batch=4)
+    fc = FusedCodec(G, H, W, max_batch=max(4, B))
     fc.load_layers(layers)
     streams = fc.encode(dev(code), dev(mask))
     for i in range(B):
