@@ -244,11 +244,11 @@ def main():
         b0 = int(codes[0].shape[0])                        # images per launch (one sub-batch)
         dom_dc = dc_t >= ec_t
         if dom_dc:
-            name, tot_ms, launches = "k_cconv4v6<4, false> (decode order, hidden layers)", dc_t, prof["dc_launches"]
+            name, tot_ms, launches = "k_cconv4v6<4, false, false> (decode order, hidden layers)", dc_t, prof["dc_launches"]
             iso_ms = iso["dc_ms"] / max(iso["dc_launches"], 1)
             bytes_per_launch = dc_hidden_bytes_per_launch(b0)
         else:
-            name, tot_ms, launches = "k_cconv4v6<4, true> (encode order, hidden layers)", ec_t, prof["ec_launches"]
+            name, tot_ms, launches = "k_cconv4v6<4, true, false> (encode order, hidden layers)", ec_t, prof["ec_launches"]
             iso_ms = iso["ec_ms"] / max(iso["ec_launches"], 1)
             bytes_per_launch = ec_hidden_bytes_per_launch(b0)
         flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)   # all hidden launches of a step cover B images x 10 layers

@@ -15,7 +15,7 @@ for path, ctr in ((fetch_csv, "FETCH_SIZE"), (write_csv, "WRITE_SIZE")):
         disp[k].add(r["Dispatch_Id"])
     for k in tot:
         res[k][ctr] = {"launches": len(disp[k]), "sum_KB": tot[k], "per_launch_KB": tot[k] / len(disp[k])}
-dom = "k_cconv4v6<4, false>"
+dom = [k for k in res if k.startswith("k_cconv4v6<4, false")][0]          # decode order, hidden layers
 rd = 2.0 * res[dom]["FETCH_SIZE"]["per_launch_KB"] * 1024
 wr = res[dom]["WRITE_SIZE"]["per_launch_KB"] * 1024
 json.dump({"command": "PB=%d rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/dc_probe.py  (one encode + one decode of %d images, "
