@@ -10,10 +10,9 @@ layers = rc.make_main_params(1003, G)
 fc = FusedCodec(G,H,W,max_batch=B); fc.load_layers(layers)
 items=[latent(np.random.default_rng(i),G,H,W) for i in range(B)]
 code=torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask=torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
-os.environ.pop("LIC360_DBG", None) if False else None
 fc.encode_async(code,mask); torch.cuda.synchronize()
 fc.profile(True)
 import time
 t0=time.time(); fc.decode_async(mask,B); torch.cuda.synchronize(); dt=time.time()-t0
 p=fc.profile_read()
-print("DBG", os.environ.get("LIC360_DBG","0"), "B", B, "dc hidden: %.1f us per launch, total %.1f ms; decode wall %.1f ms" % (1e3*p["dc_ms"]/p["dc_launches"], p["dc_ms"], dt*1e3))
+print("B", B, "dc hidden: %.1f us per launch, total %.1f ms; decode wall %.1f ms" % (1e3*p["dc_ms"]/p["dc_launches"], p["dc_ms"], dt*1e3))
