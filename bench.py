@@ -148,9 +148,9 @@ def main():
     rank, local, world = shard.init_from_env("nccl")          # one process per GPU; "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local)
 
-    import ref_codec as rc
+    from util import make_main_params, make_imp_params          # seeded synthetic weights (numpy only)
     from lic360_fused import FusedCodec
-    layers = rc.make_main_params(1000 * SSIM + MODEL_IDX, G)
+    layers = make_main_params(1000 * SSIM + MODEL_IDX, G)
     B = args.batch
     ns = max(1, min(args.streams, B))
     sizes = [B // ns + (1 if i < B % ns else 0) for i in range(ns)]
@@ -208,7 +208,7 @@ def main():
     with_imp = None
     if not args.no_importance_pass:
         from lic360_fused import FusedImpCodec
-        imp_layers = rc.make_imp_params(1000 * SSIM + MODEL_IDX)
+        imp_layers = make_imp_params(1000 * SSIM + MODEL_IDX)
         icodecs, levels, o = [], [], 0
         for sz in sizes:
             ic = FusedImpCodec(H // 2, W // 2, max_batch=sz, device=local)

@@ -3,29 +3,7 @@ CPU oracle's ops; used by the GPU parity tests, smoke() and bench.py's cpu_basel
 import numpy as np
 
 import oracle as orc
-from util import conv_params
-
-
-def make_main_params(seed, G):
-    """12 layers x 3 stacked nets [weight, sigma, mu] (lic360_demo.py:104-112,302)."""
-    rng = np.random.default_rng(seed)
-    shapes = [(G * 1, G * 4, 5, True)] + [(G * 4, G * 4, 6, True)] * 10 + [(G * 4, G * 3, 6, False)]
-    layers = []
-    for C, nout, constrain, act in shapes:
-        w, b, a = conv_params(rng, 3, nout, C, act=act)
-        layers.append(dict(w=w, b=b, a=a, constrain=constrain))
-    layers[-1]["b"][1] += 2.0          # sigma net: last bias +2 (test/model_zoo.py:263)
-    return layers
-
-
-def make_imp_params(seed, cpg=144, nsym=49):
-    rng = np.random.default_rng(seed)
-    shapes = [(1, cpg, 5, True)] + [(cpg, cpg, 6, True)] * 10 + [(cpg, nsym, 6, False)]
-    layers = []
-    for C, nout, constrain, act in shapes:
-        w, b, a = conv_params(rng, None, nout, C, act=act)
-        layers.append(dict(w=w, b=b, a=a, constrain=constrain))
-    return layers
+from util import conv_params, make_main_params, make_imp_params  # noqa: F401  (weight synthesis lives in util: no oracle needed)
 
 
 def load_into_driver(drv, layers):

@@ -23,3 +23,26 @@ def latent(rng, G, H, W):
     Lup = np.repeat(np.repeat(L, 2, 0), 2, 1)
     mask = (np.arange(G)[:, None, None] < Lup[None]).astype(np.float32)[None]
     return code, mask, L.astype(np.float32)[None, None]
+
+
+# ---- synthetic, seeded parameters of the two entropy models (no oracle involved: bench.py uses these too)
+def make_main_params(seed, G):
+    """12 layers x 3 stacked nets [weight, sigma, mu] (lic360_demo.py:104-112,302)."""
+    rng = np.random.default_rng(seed)
+    shapes = [(G * 1, G * 4, 5, True)] + [(G * 4, G * 4, 6, True)] * 10 + [(G * 4, G * 3, 6, False)]
+    layers = []
+    for C, nout, constrain, act in shapes:
+        w, b, a = conv_params(rng, 3, nout, C, act=act)
+        layers.append(dict(w=w, b=b, a=a, constrain=constrain))
+    layers[-1]["b"][1] += 2.0          # sigma net: last bias +2 (test/model_zoo.py:263)
+    return layers
+
+
+def make_imp_params(seed, cpg=144, nsym=49):
+    rng = np.random.default_rng(seed)
+    shapes = [(1, cpg, 5, True)] + [(cpg, cpg, 6, True)] * 10 + [(cpg, nsym, 6, False)]
+    layers = []
+    for C, nout, constrain, act in shapes:
+        w, b, a = conv_params(rng, None, nout, C, act=act)
+        layers.append(dict(w=w, b=b, a=a, constrain=constrain))
+    return layers
