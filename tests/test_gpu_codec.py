@@ -144,3 +144,26 @@ def test_fused_importance_codec_matches_oracle(cpg, nsym, H, W, B, seed):
     out = fc.decode(streams).cpu().numpy()
     assert np.array_equal(out, levels)
     assert np.array_equal(rc.decode_imp(streams[0], layers, H, W, nsym), levels[0:1])
+
+
+def test_fused_codec_corrupt_stream_is_reported_not_fatal():
+    """A truncated / damaged bitstream must end in an error (or a wrong-but-finite decode), never in a hang or a fault:
+    the device decoder reads zeros past the end of a stream, like the reference's BitInputStream."""
+    from lic360_fused import FusedCodec, Lic360Error
+    G, H, W, B = 6, 8, 12, 2
+    rng = np.random.default_rng(41)
+    layers = rc.make_main_params(2041, G)
+    items = [latent(rng, G, H, W) for _ in range(B)]
+    code = np.concatenate([it[0] for it in items], 0)
+    mask = np.concatenate([it[1] for it in items], 0)
+    fc = FusedCodec(G, H, W, max_batch=B)
+    fc.load_layers(layers)
+    good = fc.encode(dev(code), dev(mask))
+    damaged = [good[0][:len(good[0]) // 2], bytes(b ^ 0x5A for b in good[1])]
+    try:
+        out = fc.decode(damaged, dev(mask)).cpu().numpy()
+        assert np.isfinite(out).all() and out.min() >= 0 and out.max() <= 7
+    except Lic360Error:
+        pass
+    # the codec is still usable afterwards
+    assert np.array_equal(fc.decode(good, dev(mask)).cpu().numpy(), code * mask)
