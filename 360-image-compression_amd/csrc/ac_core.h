@@ -1,11 +1,11 @@
 // ac_core.h -- 32-bit binary arithmetic coder core, shared by the host Coder (coder_host.cpp) and
-// the device-resident coder kernels (ac_kernels.hip).  Written from the behaviour of the
+// the device-resident coder kernels (codec_fused.hip).  Written from the behaviour of the
 // reference coder (extension/ArithmeticCoder.cpp:34-69,82-116,152-170; bit order
 // extension/BitIoStream.cpp:19-34,52-71), NOT from its code: the per-bit renormalisation loops
 // are replaced by closed forms (count-leading-zeros on low^high for the shift run, count of
 // leading 01/10 pairs for the underflow run) and bits move through a 64-bit accumulator, so a
-// symbol costs O(1) instead of O(bits).  Output is byte-identical (tests/test_coder_host.py
-// against tests/golden/ac_golden.npz).
+// symbol costs O(1) instead of O(bits).  Output is byte-identical (tests/test_host_coder.py and, on the
+// device, tests/test_gpu_device_coder.py against tests/golden/ac_golden.npz).
 #pragma once
 #include <stdint.h>
 

@@ -162,16 +162,19 @@ __global__ __launch_bounds__(64) void k_ac_encode(const uint2 *__restrict__ rec,
 }
 
 // ------------------------------------------------------------------------------------------------ decode
+// the device-side stream length is never trusted: it is clamped to the stream's slot (error bit 32 flags a clamp)
+__device__ __forceinline__ long dev_stream_len(int nb, long cap) { return nb < 0 ? 0 : ((long)nb > cap ? cap : (long)nb); }
 __global__ void k_dec_init(const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes, AcDevState *__restrict__ state, int B) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     AcBitReader rd;
-    ac_br_init(rd, bytes + (long)b * cap, nbytes[b]);
+    const long len = dev_stream_len(nbytes[b], cap);
+    ac_br_init(rd, bytes + (long)b * cap, len);
     AcState st;
     ac_init(st);
     ac_decode_start(st, rd);                                          // consumes exactly 4 bytes: pos = 4, no pending bits
     AcDevState d;
-    d.low = st.low; d.high = st.high; d.code = st.code; d.error = 0; d.pad = 0;
+    d.low = st.low; d.high = st.high; d.code = st.code; d.error = (len != (long)nbytes[b]) ? 32 : 0; d.pad = 0;
     d.pos = rd.pos; d.acc = 0; d.nacc = 0;
     state[b] = d;
 }
@@ -247,6 +250,8 @@ __global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, 
     tab[((long)b * tab_pitch + i) * 2 + 1] = r1;
 }
 
+// LINEAR (test hook lic360_devcoder_decode): symbols go to code_out[b*G + start + i] instead of the latent layouts
+template <bool LINEAR>
 __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab, int tab_pitch, const int *__restrict__ idx,
                                                   int start, int len, int p, AcDevState *__restrict__ state,
                                                   const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes,
@@ -257,9 +262,9 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
     const long SK = (long)sk_rows * sk_pitch;
     AcDevState ds = state[b];
     AcState st;
-    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = ds.error;
+    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = 0;
     DevBits rd;
-    rd.buf = bytes + (long)b * cap; rd.len = nbytes[b]; rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
+    rd.buf = bytes + (long)b * cap; rd.len = dev_stream_len(nbytes[b], cap); rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
     rd.fetch_window();
     for (int base = 0; base < len; base += 64) {
         const int cnt = (len - base) < 64 ? (len - base) : 64;
@@ -289,13 +294,16 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
         }
         if (live) {
             const int q = start + base + lane;
-            const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
-            x0[((long)b * G + g) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0] = coded ? (float)symv - 3.5f : 0.0f;
-            code_out[(((long)b * G + g) * H + th) * W + tw] = coded ? (float)symv : 0.0f;
+            if constexpr (LINEAR) code_out[(long)b * G + q] = coded ? (float)symv : 0.0f;
+            else {
+                const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
+                x0[((long)b * G + g) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0] = coded ? (float)symv - 3.5f : 0.0f;
+                code_out[(((long)b * G + g) * H + th) * W + tw] = coded ? (float)symv : 0.0f;
+            }
         }
     }
     if (lane == 0) {
-        ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error = st.error;
+        ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error |= st.error;     // sticky: coder faults 1..3, clamp flag 32
         ds.pos = rd.pos; ds.acc = rd.acc; ds.nacc = rd.nacc;
         state[b] = ds;
     }
@@ -385,6 +393,8 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
     (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab);
+    for (hipEvent_t e : c->ev_ec) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_dc) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -484,7 +494,7 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
         hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_tab, c->tab_pitch,
                            B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_dec_plane, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
+        hipLaunchKernelGGL(k_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
                            c->d_x0, code_out, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
     }
@@ -551,6 +561,7 @@ __global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__
     for (int k = 0; k <= nsym; ++k) row[k] = (int)T[k];
 }
 // one wave per image: lane k holds T[k] of the current symbol; the symbol is the number of inner entries <= target
+template <bool LINEAR>
 __global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ tab, int tab_pitch, const int *__restrict__ idx, int start, int len,
                                                       AcDevState *__restrict__ state, const uint8_t *__restrict__ bytes, long cap,
                                                       const int *__restrict__ nbytes, float *__restrict__ x0, float *__restrict__ out,
@@ -559,9 +570,9 @@ __global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ ta
     const long HW = (long)H * W;
     AcDevState ds = state[b];
     AcState st;
-    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = ds.error;
+    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = 0;
     DevBits rd;
-    rd.buf = bytes + (long)b * cap; rd.len = nbytes[b]; rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
+    rd.buf = bytes + (long)b * cap; rd.len = dev_stream_len(nbytes[b], cap); rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
     rd.fetch_window();
     const int *rows = tab + (long)b * tab_pitch * IMP_TW;
     int tnext = len > 0 ? rows[lane] : 0;
@@ -574,13 +585,16 @@ __global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ ta
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(tl, sym), hi = (uint32_t)__builtin_amdgcn_readlane(tl, sym + 1);
         ac_decode_consume_from(st, rd, lo, hi, total);
         if (lane == 0) {
-            const int th = idx[start + j], tw = idx[start + j + HW];
-            x0[(long)b * (H + W - 1) * H + (long)(th + tw) * H + th] = lic360_affine((float)sym, sc, -1.0f);   // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
-            out[(long)b * HW + (long)th * W + tw] = (float)sym;
+            if constexpr (LINEAR) out[(long)b * HW + start + j] = (float)sym;
+            else {
+                const int th = idx[start + j], tw = idx[start + j + HW];
+                x0[(long)b * (H + W - 1) * H + (long)(th + tw) * H + th] = lic360_affine((float)sym, sc, -1.0f);   // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
+                out[(long)b * HW + (long)th * W + tw] = (float)sym;
+            }
         }
     }
     if (lane == 0) {
-        ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error = st.error;
+        ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error |= st.error;     // sticky: coder faults 1..3, clamp flag 32
         ds.pos = rd.pos; ds.acc = rd.acc; ds.nacc = rd.nacc;
         state[b] = ds;
     }
@@ -705,12 +719,95 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
         if (len <= 0) continue;
         hipLaunchKernelGGL(k_imp_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_imp_dec_plane, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
+        hipLaunchKernelGGL(k_imp_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
                            c->d_x0, levels_out, H, W, c->nsym, c->sc);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
     LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ device-coder test hooks
+// Raw tables + symbols through the DEVICE coder kernels (k_ac_encode, k_dec_init, k_dec_plane, k_imp_dec_plane), so that the
+// fixtures generated by the reference coder (tests/golden/ac_golden.npz) exercise the v_readlane windows, the fp32-divide
+// target and the chunked state hand-over directly.  Every table must total 65536 (what this codec's tables do).
+__global__ void k_test_records(const int *__restrict__ tables, int ncode, const int *__restrict__ labels, const float *__restrict__ mask,
+                               long n, uint2 *__restrict__ rec) {
+    GRID_STRIDE(i, n) {
+        uint2 r = make_uint2(0u, 0u);
+        if (!mask || !(mask[i] < 0.5f)) {
+            const int *T = tables + i * (ncode + 1);
+            int sym = labels[i];
+            sym = sym < 0 ? 0 : (sym > ncode - 1 ? ncode - 1 : sym);
+            r = make_uint2((unsigned)T[sym], (unsigned)T[sym + 1]);
+        }
+        rec[i] = r;
+    }
+}
+__global__ void k_test_tab8(const int *__restrict__ tables, const float *__restrict__ mask, long start, int len, uint4 *__restrict__ tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const int *T = tables + (start + i) * 9;
+    const bool coded = !mask || !(mask[start + i] < 0.5f);
+    tab[2 * i] = coded ? make_uint4(T[1], T[2], T[3], T[4]) : make_uint4(0u, 0u, 0u, 0u);
+    tab[2 * i + 1] = coded ? make_uint4(T[5], T[6], T[7], 1u) : make_uint4(0u, 0u, 0u, 0u);
+}
+__global__ void k_test_tabn(const int *__restrict__ tables, int ncode, long start, int len, int *__restrict__ tab) {
+    const int i = blockIdx.x, k = threadIdx.x;
+    if (i < len && k <= ncode) tab[(long)i * IMP_TW + k] = tables[(start + i) * (ncode + 1) + k];
+}
+
+LIC360_API int lic360_devcoder_encode(void *stream, const int *tables, int ncode, const int *labels, const float *mask, long n,
+                                      uint8_t *bytes, long cap, int *nbytes, int *err) {
+    ARG_CHECK(ncode >= 1 && n >= 0 && bytes && nbytes && err && cap > 0 && (n == 0 || (tables && labels)));
+    hipStream_t s = (hipStream_t)stream;
+    uint2 *rec = nullptr;
+    if (dmalloc(&rec, (size_t)n)) return 1;
+    if (n) {
+        hipLaunchKernelGGL(k_test_records, dim3(lic360_blocks(n, 1)), dim3(256), 0, s, tables, ncode, labels, mask, n, rec);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_ac_encode, dim3(1), dim3(64), 0, s, rec, n, bytes, cap, nbytes, err);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(rec);
+    return 0;
+}
+
+// decodes n symbols in consecutive chunks of `chunk` symbols -- the role planes play in the codec: coder state and bit
+// position are handed from launch to launch through AcDevState.  ncode == 8 runs k_dec_plane (8-symbol GMM tables as two
+// uint4 + coded flag), any other alphabet (< 64) k_imp_dec_plane (one table entry per lane).  out[i] = symbol, 0 where masked.
+LIC360_API int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const float *mask, long n, int chunk,
+                                      const uint8_t *bytes, long cap, const int *nbytes, float *out, int *err) {
+    ARG_CHECK(ncode >= 1 && ncode < IMP_TW && n >= 0 && chunk > 0 && bytes && nbytes && out && err && cap > 0 && cap % 4 == 0 &&
+              ((uintptr_t)bytes & 3) == 0 && (n == 0 || tables) && (ncode == 8 || !mask));
+    hipStream_t s = (hipStream_t)stream;
+    AcDevState *st = nullptr;
+    uint4 *tab8 = nullptr;
+    int *tabn = nullptr;
+    if (dmalloc(&st, 1) || dmalloc(&tab8, 2 * (size_t)chunk) || dmalloc(&tabn, (size_t)chunk * IMP_TW)) return 1;
+    hipLaunchKernelGGL(k_dec_init, dim3(1), dim3(64), 0, s, bytes, cap, nbytes, st, 1);
+    LAUNCH_CHECK();
+    for (long start = 0; start < n; start += chunk) {
+        const int len = (int)std::min<long>(chunk, n - start);
+        if (ncode == 8) {
+            hipLaunchKernelGGL(k_test_tab8, dim3((len + 63) / 64), dim3(64), 0, s, tables, mask, start, len, tab8);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_dec_plane<true>, dim3(1), dim3(64), 0, s, tab8, chunk, (const int *)nullptr, (int)start, len, 0, st, bytes, cap, nbytes,
+                               (float *)nullptr, out, 0, 1, 1, 0, 0, 0, 0);
+        } else {
+            hipLaunchKernelGGL(k_test_tabn, dim3(len), dim3(64), 0, s, tables, ncode, start, len, tabn);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_imp_dec_plane<true>, dim3(1), dim3(64), 0, s, tabn, chunk, (const int *)nullptr, (int)start, len, st, bytes, cap, nbytes,
+                               (float *)nullptr, out, 0, 0, ncode, 0.0f);
+        }
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_collect_err, dim3(1), dim3(64), 0, s, st, err, 1);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(st); (void)hipFree(tab8); (void)hipFree(tabn);
     return 0;
 }
 

@@ -12,7 +12,6 @@ import torch
 import lic360
 from lic360 import _lib, _chk, _p, _stream, Lic360Error
 
-_lib.lic360_codec_destroy.argtypes = [C.c_void_p]
 
 
 class FusedCodec(object):

@@ -197,6 +197,16 @@ int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int layer, const
 int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const float *levels, int B, uint8_t *bytes, long cap, int *nbytes, int *err);
 int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B, float *levels_out, int *err);
 
+/* Test hooks of the DEVICE arithmetic coder (A19/A20 as they run inside the fused codec): raw int32 tables [n][ncode+1]
+ * (every table totals 65536), labels and an optional mask, all in device memory, through the same kernels the codec
+ * launches -- encode: k_ac_encode; decode: k_dec_init + k_dec_plane (ncode == 8) or k_imp_dec_plane (other alphabets),
+ * `chunk` symbols per launch with the coder state carried between launches like between planes.  Reference behaviour:
+ * extension/coder.cpp:30-113 over extension/ArithmeticCoder.cpp:34-116.  Synchronises the stream before returning. */
+int lic360_devcoder_encode(void *stream, const int *tables, int ncode, const int *labels, const float *mask, long n,
+                           uint8_t *bytes, long cap, int *nbytes, int *err);
+int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const float *mask, long n, int chunk,
+                           const uint8_t *bytes, long cap, const int *nbytes, float *out, int *err);
+
 /* timing hooks for bench.py: HIP events around every hidden-layer conv launch (encode-order / decode-order),
  * recorded on the caller's stream; read() returns the summed elapsed ms + launch counts and resets */
 int lic360_codec_profile_enable(lic360_codec *codec, int on);

@@ -276,6 +276,11 @@ ORC_API void orc_gmm_table_batch(float *data, long stride, float *out, int tn, i
     if (tn > 0) gmm_rows(data, data + stride, data + 2 * stride, out, tn, ng, nstep, bias, total, beta);
 }
 
+/* elementwise views of the shared exp / erf (tests/independent_tables.py takes the transcendental VALUES from here and
+ * restates everything around them -- summation order, divisions, double-precision rounding, clamp, fix-up -- on its own) */
+ORC_API void orc_expf_v(const float *x, float *y, long n) { for (long i = 0; i < n; ++i) y[i] = lic360_expf(x[i]); }
+ORC_API void orc_erff_v(const float *x, float *y, long n) { for (long i = 0; i < n; ++i) y[i] = lic360_erff(x[i]); }
+
 /* A15 entropy_table                         extension/entropy_table_cuda.cu:24-96 */
 ORC_API void orc_entropy_table(const float *data, float *out, int count, int nstep, float total) {
     float tmp[64];

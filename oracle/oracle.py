@@ -142,6 +142,24 @@ def entropy_table(data, count, nstep, total=65536.0):
     return out[:count]
 
 
+lib.orc_expf_v.argtypes = [_f, _f, C.c_long]
+lib.orc_erff_v.argtypes = [_f, _f, C.c_long]
+
+
+def expf(x):
+    x = f32(np.atleast_1d(x))
+    y = np.empty_like(x)
+    lib.orc_expf_v(x.reshape(-1), y.reshape(-1), x.size)
+    return y
+
+
+def erff(x):
+    x = f32(np.atleast_1d(x))
+    y = np.empty_like(x)
+    lib.orc_erff_v(x.reshape(-1), y.reshape(-1), x.size)
+    return y
+
+
 def entropy_gmm(weight, delta, mean, label):
     M, ng = weight.shape
     loss = np.zeros(M, np.float32)

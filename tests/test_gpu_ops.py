@@ -395,3 +395,34 @@ def test_cconv4_ec_diag_bit_exact(lic, case):
     got = host(out)[:N * nout * maps[0] * maps[1]].reshape(N, nout, maps[0], maps[1])
     L.lic360_conv_plan_destroy(plan)
     assert np.array_equal(got, _to_ec6(ref, maps)), "wrapped-diagonal output (with its repeated rows and zero padding) differs"
+
+
+def test_conv_ops_follow_weight_data_writes(lic):
+    """`param.data.copy_()` does not bump `param._version` (the reference's own QUANT init writes that way): the packed-weight
+    cache must not serve stale weights -- encode order repacks per call, decode order at the start of every sweep."""
+    rng = np.random.default_rng(3)
+    G, cin, cout, H, W = 6, 4, 4, 6, 9
+    C, nout = G * cin, G * cout
+    w1, b, a = conv_params(rng, 3, nout, C, act=True)
+    w2 = (w1 * np.float32(0.5) + np.float32(0.01)).astype(np.float32)
+    x = rng.standard_normal((3, C, H, W)).astype(np.float32)
+    wt = torch.nn.Parameter(dev(w1), requires_grad=False)
+    xd, bd, ad = dev(x), dev(b), dev(a)
+    op = lic.CconvEcOp(C, G, nout, 5, 6, 0, False)
+    assert np.array_equal(host(op.forward_act_batch(xd, wt, bd, ad)[0]), orc.cconv_ec(x, w1, b, a, G, 6))
+    v = wt._version
+    wt.data.copy_(dev(w2))
+    assert wt._version == v                                          # the trap this test is about
+    assert np.array_equal(host(op.forward_act_batch(xd, wt, bd, ad)[0]), orc.cconv_ec(x, w2, b, a, G, 6))
+    # decode order: a new sweep (restart) sees the new weights
+    ctx = lic.CodeContexOp(0, False)
+    p1, p2 = ctx.forward(xd)
+    dc = lic.CconvDcOp(C, G, nout, 5, 6, 0, False)
+    dc.set_param(p1, p2)
+    for wnp in (w1, w2):
+        wt.data.copy_(dev(wnp))
+        dc.restart()
+        out = None
+        for p in range(H + W + G - 2):
+            out = dc.forward_act_batch(xd, wt, bd, ad)[0]
+        assert np.array_equal(host(out), orc.cconv_ec(x, wnp, b, a, G, 6))
