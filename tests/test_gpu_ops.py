@@ -426,3 +426,28 @@ def test_conv_ops_follow_weight_data_writes(lic):
         for p in range(H + W + G - 2):
             out = dc.forward_act_batch(xd, wt, bd, ad)[0]
         assert np.array_equal(host(out), orc.cconv_ec(x, wnp, b, a, G, 6))
+
+
+def test_operator_extras_plain_torch(lic):
+    """GDN / DropGrad / SSIM of lic360_operator (plain torch, outside the accelerated path): formula-level checks."""
+    import lic360_operator as lo
+    torch.manual_seed(0)
+    x = torch.randn(2, 6, 5, 7, device="cuda:0")
+    for inverse in (False, True):
+        g = lo.GDN(6, 0, inverse)
+        with torch.no_grad():
+            g.gamma.add_(0.05 * torch.rand_like(g.gamma))
+        ped = (2.0 ** -18) ** 2
+        beta = g.beta.clamp_min((1e-6 + ped) ** 0.5) ** 2 - ped
+        gamma = g.gamma.clamp_min(2.0 ** -18) ** 2 - ped
+        norm = torch.sqrt(torch.einsum("ij,njhw->nihw", gamma, x * x) + beta[None, :, None, None])
+        want = x * norm if inverse else x / norm
+        assert torch.allclose(g(x), want, rtol=1e-5, atol=1e-6)
+        assert set(dict(g.named_parameters())) == {"beta", "gamma"}
+    a = torch.rand(1, 3, 32, 32, device="cuda:0")
+    assert abs(float(lo.SSIM()(a, a)) - 1.0) < 1e-5 and float(lo.SSIM()(a, 1 - a)) < 0.5
+    y = torch.ones(3, device="cuda:0", requires_grad=True)
+    lo.DropGrad(True)(y).sum().backward()
+    assert float(y.grad.abs().sum()) == 0.0
+    with pytest.raises(NotImplementedError):
+        lo.MultiProject(171, 171)
