@@ -24,6 +24,10 @@ struct AcDevState {            // per-image decoder state carried across planes
     unsigned long long acc;
 };
 
+enum { PROF_EC_FIRST, PROF_EC_HIDDEN, PROF_EC_LAST, PROF_ENC_TABLES, PROF_AC_ENCODE,
+       PROF_DC_FIRST, PROF_DC_HIDDEN, PROF_DC_LAST, PROF_DEC_TABLES, PROF_DEC_PLANE, PROF_NCLS };
+static const char *const PROF_NAMES = "ec_first,ec_hidden,ec_last,enc_tables,ac_encode,dc_first,dc_hidden,dc_last,dec_tables,dec_plane";
+
 struct lic360_codec {
     int G, H, W, maxB, S, P, HW;
     int sk_rows, sk_pitch, sk_row0, sk_col0;
@@ -42,22 +46,26 @@ struct lic360_codec {
     uint4 *d_tab = nullptr;                    // per-plane CDF tables [maxB][tab_pitch] (k_dec_tables -> k_dec_plane)
     int tab_pitch = 0;
     bool layer_set[12];
-    // optional per-kernel timing of the hidden-layer conv launches (bench.py roofline leg)
+    // optional per-kernel-class timing (bench.py's instrumented pass; off in the timed region): HIP event pairs around
+    // every launch of a class, recorded on the launch stream
     bool prof = false;
-    std::vector<hipEvent_t> ev_ec, ev_dc;      // start/stop pairs
-    size_t n_ec = 0, n_dc = 0;
+    std::vector<hipEvent_t> ev[PROF_NCLS];     // start/stop pairs
+    size_t n_ev[PROF_NCLS] = {};
 };
 
-static int prof_mark(lic360_codec *c, std::vector<hipEvent_t> &pool, size_t &n, hipStream_t s) {
+static int prof_mark(lic360_codec *c, int cls, hipStream_t s) {
     if (!c->prof) return 0;
-    if (n >= pool.size()) {
+    std::vector<hipEvent_t> &pool = c->ev[cls];
+    if (c->n_ev[cls] >= pool.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         pool.push_back(e);
     }
-    HIP_TRY(hipEventRecord(pool[n++], s));
+    HIP_TRY(hipEventRecord(pool[c->n_ev[cls]++], s));
     return 0;
 }
+// brackets one launch (or launch group) of class CLS
+#define PROF(c, CLS, s, ...) do { prof_mark(c, CLS, s); __VA_ARGS__; prof_mark(c, CLS, s); } while (0)
 
 static int plan_of(int layer) { return layer == 0 ? 0 : (layer == 11 ? 2 : 1); }
 
@@ -393,8 +401,8 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
     (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab);
-    for (hipEvent_t e : c->ev_ec) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_dc) (void)hipEventDestroy(e);
+    for (int k = 0; k < PROF_NCLS; ++k)
+        for (hipEvent_t e : c->ev[k]) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -440,22 +448,21 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
         if (c->use4) return lic360_cconv4_ec_padded(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
         return lic360_cconv_ec_ex(stream, p, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
     };
-    if (ec(0, c->e_x0, nullptr, cur, B)) return 1;
-    for (int blk = 0; blk < 5; ++blk) {
+    int rc = 0;
+    PROF(c, PROF_EC_FIRST, s, rc |= ec(0, c->e_x0, nullptr, cur, B));
+    for (int blk = 0; blk < 5 && !rc; ++blk) {
         int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
-        prof_mark(c, c->ev_ec, c->n_ec, s);
-        if (ec(a, cur, nullptr, t1, 3 * B)) return 1;
-        prof_mark(c, c->ev_ec, c->n_ec, s);
-        prof_mark(c, c->ev_ec, c->n_ec, s);
-        if (ec(b2, t1, cur, nxt, 3 * B)) return 1;
-        prof_mark(c, c->ev_ec, c->n_ec, s);
+        PROF(c, PROF_EC_HIDDEN, s, rc |= ec(a, cur, nullptr, t1, 3 * B));
+        PROF(c, PROF_EC_HIDDEN, s, rc |= ec(b2, t1, cur, nxt, 3 * B));
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
-    if (ec(11, cur, nullptr, t1, 3 * B)) return 1;
-    hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx, c->d_plane_start,
-                       c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp);
+    if (rc) return 1;
+    PROF(c, PROF_EC_LAST, s, rc |= ec(11, cur, nullptr, t1, 3 * B));
+    if (rc) return 1;
+    PROF(c, PROF_ENC_TABLES, s, hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx,
+                                                   c->d_plane_start, c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp));
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err);
+    PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
     LAUNCH_CHECK();
     return 0;
 }
@@ -477,25 +484,25 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     };
     for (int p = 0; p < c->P; ++p) {
         // plane p of all 12 layers (x0 already holds planes < p)
-        if (dc(0, c->d_x0, nullptr, c->d_act[0], B, p)) return 1;
-        for (int blk = 0; blk < 5; ++blk) {
+        int rc = 0;
+        PROF(c, PROF_DC_FIRST, s, rc |= dc(0, c->d_x0, nullptr, c->d_act[0], B, p));
+        for (int blk = 0; blk < 5 && !rc; ++blk) {
             int a = 1 + 2 * blk, b2 = 2 + 2 * blk;
-            prof_mark(c, c->ev_dc, c->n_dc, s);
-            if (dc(a, c->d_act[a - 1], nullptr, c->d_act[a], 3 * B, p)) return 1;
-            prof_mark(c, c->ev_dc, c->n_dc, s);
-            prof_mark(c, c->ev_dc, c->n_dc, s);
-            if (dc(b2, c->d_act[a], c->d_act[a - 1], c->d_act[b2], 3 * B, p)) return 1;
-            prof_mark(c, c->ev_dc, c->n_dc, s);
+            PROF(c, PROF_DC_HIDDEN, s, rc |= dc(a, c->d_act[a - 1], nullptr, c->d_act[a], 3 * B, p));
+            PROF(c, PROF_DC_HIDDEN, s, rc |= dc(b2, c->d_act[a], c->d_act[a - 1], c->d_act[b2], 3 * B, p));
         }
-        if (dc(11, c->d_act[10], nullptr, c->d_y, 3 * B, p)) return 1;
+        if (rc) return 1;
+        PROF(c, PROF_DC_LAST, s, rc |= dc(11, c->d_act[10], nullptr, c->d_y, 3 * B, p));
+        if (rc) return 1;
         int start, len;
         lic360_plane_window(p, G, H, W, pih, &start, &len);
         if (len <= 0) continue;
-        hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p, c->d_tab, c->tab_pitch,
-                           B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        PROF(c, PROF_DEC_TABLES, s, hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p,
+                                                       c->d_tab, c->tab_pitch, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0));
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, p, c->d_state, bytes, cap, nbytes,
-                           c->d_x0, code_out, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        PROF(c, PROF_DEC_PLANE, s, hipLaunchKernelGGL(k_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, p,
+                                                      c->d_state, bytes, cap, nbytes, c->d_x0, code_out, G, H, W, c->sk_rows, c->sk_pitch,
+                                                      c->sk_row0, c->sk_col0));
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
@@ -815,27 +822,28 @@ LIC360_API int lic360_devcoder_decode(void *stream, const int *tables, int ncode
 LIC360_API int lic360_codec_profile_enable(lic360_codec *c, int on) {
     ARG_CHECK(c);
     c->prof = on != 0;
-    c->n_ec = c->n_dc = 0;
+    for (int k = 0; k < PROF_NCLS; ++k) c->n_ev[k] = 0;
     return 0;
 }
+// comma-separated names of the kernel classes, in the order lic360_codec_profile_read fills its arrays
+LIC360_API const char *lic360_codec_profile_classes(void) { return PROF_NAMES; }
 
-// Sum of HIP-event elapsed times (ms) and launch counts of the hidden-layer conv kernels recorded since the
-// last call; the events were recorded on the stream the kernels ran on.  Synchronises on the last event.
-LIC360_API int lic360_codec_profile_read(lic360_codec *c, double *ec_ms, long *ec_launches, double *dc_ms, long *dc_launches) {
-    ARG_CHECK(c && ec_ms && ec_launches && dc_ms && dc_launches);
-    double acc[2] = {0, 0};
-    std::vector<hipEvent_t> *pools[2] = {&c->ev_ec, &c->ev_dc};
-    size_t cnt[2] = {c->n_ec, c->n_dc};
-    for (int k = 0; k < 2; ++k) {
-        for (size_t i = 0; i + 1 < cnt[k]; i += 2) {
-            HIP_TRY(hipEventSynchronize((*pools[k])[i + 1]));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, (*pools[k])[i], (*pools[k])[i + 1]));
-            acc[k] += ms;
+// Per kernel class: sum of HIP-event elapsed times (ms) and number of launches recorded since the last call; the events
+// were recorded on the stream the kernels ran on.  ms / launches must hold `n` entries (n >= number of classes, else error).
+LIC360_API int lic360_codec_profile_read(lic360_codec *c, int n, double *ms, long *launches) {
+    ARG_CHECK(c && ms && launches && n >= PROF_NCLS);
+    for (int k = 0; k < PROF_NCLS; ++k) {
+        double acc = 0;
+        const size_t cnt = c->n_ev[k];
+        for (size_t i = 0; i + 1 < cnt; i += 2) {
+            HIP_TRY(hipEventSynchronize(c->ev[k][i + 1]));
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev[k][i], c->ev[k][i + 1]));
+            acc += t;
         }
+        ms[k] = acc;
+        launches[k] = (long)(cnt / 2);
+        c->n_ev[k] = 0;
     }
-    *ec_ms = acc[0]; *ec_launches = (long)(cnt[0] / 2);
-    *dc_ms = acc[1]; *dc_launches = (long)(cnt[1] / 2);
-    c->n_ec = c->n_dc = 0;
     return 0;
 }

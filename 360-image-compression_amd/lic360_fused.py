@@ -117,10 +117,12 @@ class FusedCodec(object):
         _chk(_lib.lic360_codec_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        ec, dc = C.c_double(0), C.c_double(0)
-        nec, ndc = C.c_long(0), C.c_long(0)
-        _chk(_lib.lic360_codec_profile_read(self._h, C.byref(ec), C.byref(nec), C.byref(dc), C.byref(ndc)))
-        return dict(ec_ms=ec.value, ec_launches=nec.value, dc_ms=dc.value, dc_launches=ndc.value)
+        """-> {kernel class: (total ms, launches)} since the last call (classes: lic360_codec_profile_classes)."""
+        names = _lib.lic360_codec_profile_classes().decode().split(",")
+        ms = (C.c_double * len(names))()
+        cnt = (C.c_long * len(names))()
+        _chk(_lib.lic360_codec_profile_read(self._h, len(names), ms, cnt))
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(names)}
 
 
 class FusedImpCodec(object):

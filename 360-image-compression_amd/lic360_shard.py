@@ -4,6 +4,9 @@ cross-rank operations are the barrier + MAX of the wall time used for throughput
 of per-image results (bitstream sizes / digests) to rank 0.  Works with backend "nccl" (= RCCL on ROCm) on GPUs and
 "gloo" on CPU (tests)."""
 import os
+import socket
+import subprocess
+import sys
 import time
 
 import torch
@@ -13,6 +16,25 @@ import torch.distributed as dist
 def shard_indices(n_items, rank, world):
     """Images handled by `rank`: i = rank, rank+world, ... (round-robin keeps shards within one image of each other)."""
     return list(range(rank, n_items, world))
+
+
+def launch_ranks(script, argv, nproc, extra_env=None):
+    """Start `nproc` ranks of `script argv...` on this node, one process per GPU, exactly as the driver does it:
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script ...`.
+    Call it from a process that has made NO HIP call yet (a parent that has touched the GPU must not be replaced, and a
+    child forked after HIP initialisation inherits a broken context): the caller stays a plain supervisor and returns
+    the launcher's exit code.  Rank 0's stdout is the caller's stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def init_from_env(backend=None):

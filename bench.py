@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- ERP Mpixels/s enc+dec @512x1024, model-idx 3 (BASELINE.json metric) on N MI355X of one node.
 
-One "step" = one pass of the hot path over one batch of synthetic images per GPU: encode the quantised
-latents (code, mask resident in HBM) into bitstreams (HBM) and decode those bitstreams back, through the
-device-resident codec (lic360_fused.FusedCodec -> liblic360_hip.so).  Images shard one-per-slot across the
-GPUs with no data-path collective: every rank runs the same per-GPU batch ("weak" scaling);
-the only cross-rank traffic is the barrier + MAX of the wall time.
+  python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task description), with
-  roofline:     dominant kernel = the hidden-layer masked conv (encode order or decode order, whichever took more
-                time).  Its binding roofline is the fp32 MFMA peak: the MACs of a launch take longer at 157 TFLOP/s
-                than its algorithmic bytes (the 9-diagonal halo of every live group, read once) take at 8 TB/s.
-                achieved = algorithmic FLOPs per launch / mean launch duration from HIP events recorded on the
-                launch stream during the timed steps; the HBM view of the same launches (algorithmic bytes and the
-                measured PMC traffic) is reported next to it;
-  cpu_baseline: the CPU oracle (oracle/, OpenMP over output scalars) on a bounded crop of the same workload.
+One "step" = one pass of the hot path over one batch of synthetic images per GPU: BOTH bitstreams of every image -- the
+quantised latent (48x64x128 symbols under its importance mask) and the 32x64 importance map, what the reference's
+encoding()/decoding() code (test/lic360_demo.py:357-366, 394-402) -- are encoded into HBM-resident bitstreams and decoded
+back through the device-resident codecs (lic360_fused -> liblic360_hip.so).  Images shard one-per-slot across the GPUs
+with no data-path collective: every rank runs the same per-GPU batch ("weak" scaling); the only cross-rank
+traffic is the barrier + MAX of the wall time.
+
+Launch: with `--gpus N > 1` and no WORLD_SIZE in the environment, this process makes NO HIP call and starts N ranks as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`
+(lic360_shard.launch_ranks), which is also how the driver launches it; every rank asserts WORLD_SIZE == --gpus.
+
+Rank 0 prints ONE JSON line (contract in the task description) with, besides the headline:
+  roofline      the dominant kernel (the conv kernel class with the most GPU time), measured ALONE on the GPU: one sub-batch,
+                one stream, HIP events around every launch on the launch stream (an instrumented pass outside the timed
+                region; the timed region runs with instrumentation off).  `concurrent` repeats it with all streams running.
+  kernels       one row per kernel class of the codec (conv first/hidden/last in both orders against the fp32 MFMA peak,
+                table builds against the HBM peak, the serial coder kernels as ns per symbol) + the streaming ops (GB/s)
+  single_image  BASELINE.json configs[1]/[2]: latency of one image alone (encode, decode)
+  config4       BASELINE.json configs[3]: a fixed list of 64 images sharded i -> rank i mod N (strong scaling figure)
+  cpu_baseline  rank 0, N = 1: the CPU oracle on ONE WHOLE image of the same workload (encode + decode); the same leg
+                asserts that the GPU's bitstream of that image equals the oracle's byte for byte.
 """
 import argparse
 import json
@@ -23,64 +32,40 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "360-image-compression_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "360-image-compression_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# the oracle's OpenMP pool: the GPU box gives one GPU a 16-core CPU share
-os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 G, H, W = 48, 64, 128                   # entropy-domain tensor of a 512x1024 ERP
+NSYM = G * H * W
+PLANES = H + W + G - 2
 PIXELS = 512 * 1024
 MODEL_IDX, SSIM = 3, 1
-# algorithmic work per image, exact counts from the mask rule (SURVEY.md §8d / BASELINE.md §3)
-HIDDEN_GMAC = 11.23                     # one hidden layer, 3 stacked nets
-NET_GMAC = 123.42                       # the whole 12-layer x 3-net latent entropy model, one direction
+# algorithmic work per image and direction, exact counts from the mask rule: GMAC of the 3 stacked nets
+GMAC = {"first": 2.70, "hidden": 11.23 * 10, "last": 8.42}
+NET_GMAC = 123.42
+IMP_GMAC = 6.22
 F32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md: fp32 MFMA dense peak
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def chain_len(g, hidden=1):
-    """input groups group g reads in a hidden layer (extension/cconv_ec_cuda.cu:288-290, longest lane)"""
-    return min(G, g + 4 + hidden)
-
-
-def dc_hidden_bytes_per_launch(b):
-    """Algorithmic HBM bytes of one decode-order hidden-layer launch (one anti-diagonal plane, 3*b sample-nets), averaged
-    over the planes: every input (channel, diagonal) a live group needs is read once, every output written once, half of
-    the hidden layers read a residual, the weights of the live groups are read once."""
-    S, n = H + W - 1, 3 * b
-    lens = [min(s, H - 1) - max(0, s - W + 1) + 1 for s in range(S)]
-    tot, launches = 0.0, 0
-    for p in range(S + G - 1):
-        live = [g for g in range(G) if 0 <= p - g < S]
-        if not live:
-            continue
-        launches += 1
-        inb = 0
-        for tc in range(G):
-            rows = set()
-            for g in live:
-                if tc < chain_len(g):
-                    rows.update(s for s in range(p - g - 4, p - g + 5) if 0 <= s < S)
-            inb += 4 * sum(lens[s] for s in rows)
-        outb = sum(4 * lens[p - g] for g in live)
-        wb = 3 * sum(chain_len(g) * 400 for g in live)
-        tot += 4.0 * (n * (inb + 1.5 * outb) + wb)
-    return tot / launches
-
-
-def ec_hidden_bytes_per_launch(b):
-    """Algorithmic HBM bytes of one encode-order hidden-layer launch: activations in, activations out (+ residual for
-    half of the layers), weights once."""
-    n = 3 * b
-    return 4.0 * (n * 4 * G * H * W * 2.5 + 3 * sum(chain_len(g) * 400 for g in range(G)))
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=144, help="images per GPU per step: 144 resident images (3 sub-batches of 48) keep the "
+                    "decode wavefront wide enough to fill 256 CUs (BASELINE.json configs[3] is the 8-per-GPU form: see `config4`)")
+    ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
+                    "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip latent-only pass, single image, config4, streaming ops)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch / sharding / reporting path on gloo: no codec work, value 0")
+    return ap.parse_args()
 
 
 def synth_latents(batch, seed0):
+    import numpy as np
     from util import latent
     codes, masks, levels = [], [], []
     for i in range(batch):
@@ -91,211 +76,283 @@ def synth_latents(batch, seed0):
     return np.concatenate(codes, 0), np.concatenate(masks, 0), np.concatenate(levels, 0)
 
 
-def cpu_baseline(layers):
-    """Oracle enc+dec of four 32x32 latent crops (together half an image's symbols: full 48-group, 12-layer, 3-net model)."""
+def cpu_baseline(layers, imp_layers, code, mask, levels, gpu_bytes, gpu_imp_bytes):
+    """The CPU oracle (oracle/, test infrastructure) on ONE WHOLE image: encode + decode of both streams, OpenMP over the
+    output scalars of each layer with every host core of this GPU's share.  Also the checker of the timed data: the GPU's
+    bitstreams of this image must equal the oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import ref_codec as rc
-    from util import latent
-    ch, cw, reps = 32, 32, 4
-    t0 = time.time()
-    for i in range(reps):
-        code, mask, _ = latent(np.random.default_rng(99 + i), G, ch, cw)
-        data = rc.encode_main(code, mask, layers, G)
-        out = rc.decode_main(data, mask, layers, G)
-        assert np.array_equal(out, code * mask)
-    dt = time.time() - t0
-    px = reps * PIXELS * (ch * cw) / float(H * W)
     cores = int(os.environ["OMP_NUM_THREADS"])
-    # single-thread arithmetic coder alone (SURVEY.md §8d): config-1 workload, 393 216 symbols on per-symbol 9-entry tables
-    import oracle as orc
-    rng = np.random.default_rng(5)
-    nsym = G * H * W
-    inner = np.sort(rng.integers(1, 65535, (nsym, 7)), axis=1) + np.arange(7)
-    tab = np.concatenate([np.zeros((nsym, 1), np.int64), inner, np.full((nsym, 1), 65536 + 7, np.int64)], 1).astype(np.int32)
-    sym = rng.integers(0, 8, nsym).astype(np.int32)
+    t0 = time.time()
+    data = rc.encode_main(code, mask, layers, G)
+    imp = rc.encode_imp(levels, imp_layers)
     t1 = time.time()
-    enc = orc.Encoder()
-    enc.encode(tab, 8, sym, None, nsym)
-    data = enc.finish()
+    out = rc.decode_main(data, mask, layers, G)
+    lv = rc.decode_imp(imp, imp_layers, H // 2, W // 2)
     t2 = time.time()
-    dec = orc.Decoder(data)
-    out = dec.decode(tab, 8, None, nsym)
-    dec.close()
-    t3 = time.time()
-    assert np.array_equal(out.astype(np.int32), sym)
-    return {"value": px / dt / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
-            "coder_single_thread_Msym_per_s": {"encode": nsym / (t2 - t1) / 1e6, "decode": nsym / (t3 - t2) / 1e6},
-            "sample": "oracle enc+dec of %d latent crops of %dx%d (=%d px of 512x1024 ERPs), full 12-layer x3 model, %.1f s" % (reps, ch, cw, int(px), dt)}
+    assert np.array_equal(out, code * mask) and np.array_equal(lv, levels)
+    same = bool(data == gpu_bytes and imp == gpu_imp_bytes)
+    assert same, "GPU bitstream of image 0 differs from the oracle's"
+    return {"value": PIXELS / (t2 - t0) / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "encode_s": t1 - t0, "decode_s": t2 - t1, "gpu_bytes_equal_oracle_bytes": same,
+            "sample": "oracle encode + decode of ONE whole 512x1024 image of the timed batch (image 0: latent 48x64x128 + 32x64 importance "
+                      "map, full 12-layer x3 model), %.1f s on %d threads" % (t2 - t0, cores)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=144, help="images per GPU per step (BASELINE.json configs[3] shards a 64-image batch; "
-                    "144 resident images per GPU (3 sub-batches of 48, 52 GB of the 288 GB) keep the decode wavefront wide enough to fill "
-                    "256 CUs: 96 -> 42.2, 144 -> 43.9, 192 -> 44.3 Mpixel/s)")
-    ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
-                    "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-importance-pass", action="store_true", help="skip the extra (untimed for `value`) pass that also codes the importance maps")
-    args = ap.parse_args()
-
+def dry_run(args):
+    """gloo rehearsal of everything around the codec: rank set-up, sharding of config 4's image list, fences, MAX timing."""
     import lic360_shard as shard
     import torch.distributed as dist
+    rank, local, world = shard.init_from_env("gloo")
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    mine = shard.shard_indices(64, rank, world)
+    dt = shard.timed(lambda: time.sleep(0.01 * len(mine) / 8.0), args.steps)
+    parts = shard.gather_results({i: rank for i in mine}, 64)
+    if rank == 0:
+        assert sorted(set(parts)) == list(range(world))
+        print(json.dumps({"metric": "ERP Mpixels/s enc+dec @512x1024 model-idx 3; bitstream bit-exact vs ref", "value": 0.0, "unit": "Mpixel/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)",
+                          "config": {"workload": "dry run: launch / sharding / reporting path only", "images_per_rank_config4": len(mine)}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))     # the oracle's pool (cpu_baseline leg only)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import lic360_shard as shard
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     rank, local, world = shard.init_from_env("nccl")          # one process per GPU; "nccl" is RCCL on ROCm
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d: start the ranks with `bench.py --gpus N` or torch.distributed.run" % (world, args.gpus)
     dev = torch.device("cuda", local)
 
     from util import make_main_params, make_imp_params          # seeded synthetic weights (numpy only)
-    from lic360_fused import FusedCodec
-    layers = make_main_params(1000 * SSIM + MODEL_IDX, G)
+    from lic360_fused import FusedCodec, FusedImpCodec
+    wseed = 1000 * SSIM + MODEL_IDX
+    layers, imp_layers = make_main_params(wseed, G), make_imp_params(wseed)
     B = args.batch
     ns = max(1, min(args.streams, B))
     sizes = [B // ns + (1 if i < B % ns else 0) for i in range(ns)]
     code_np, mask_np, level_np = synth_latents(B, seed0=1000 * rank)
-    codecs, codes, masks, streams = [], [], [], []
+    codecs, icodecs, codes, masks, levels, streams = [], [], [], [], [], []
     o = 0
     for sz in sizes:
         c = FusedCodec(G, H, W, max_batch=sz, device=local)
         c.load_layers(layers)
+        ic = FusedImpCodec(H // 2, W // 2, max_batch=sz, device=local)
+        ic.load_layers(imp_layers)
         codecs.append(c)
+        icodecs.append(ic)
         codes.append(torch.from_numpy(code_np[o:o + sz]).to(dev))
         masks.append(torch.from_numpy(mask_np[o:o + sz]).to(dev))
+        levels.append(torch.from_numpy(level_np[o:o + sz]).to(dev))
         streams.append(torch.cuda.Stream(device=dev))
         o += sz
     torch.cuda.synchronize(dev)
 
-    def step():
-        for c, cd, mk, st in zip(codecs, codes, masks, streams):
-            with torch.cuda.stream(st):
-                c.encode_async(cd, mk)
-        for c, cd, mk, st in zip(codecs, codes, masks, streams):
-            with torch.cuda.stream(st):
-                c.decode_async(mk, cd.shape[0])
+    def run(cds, mks, lvs, imp=True):
+        """encode then decode of one list of sub-batches (one per stream); inputs resident in HBM, bitstreams stay in HBM"""
+        for c, ic, cd, mk, lv, st in zip(codecs, icodecs, cds, mks, lvs, streams):
+            if cd.shape[0]:
+                with torch.cuda.stream(st):
+                    if imp:
+                        ic.encode_async(lv)
+                    c.encode_async(cd, mk)
+        for c, ic, cd, mk, lv, st in zip(codecs, icodecs, cds, mks, lvs, streams):
+            if cd.shape[0]:
+                with torch.cuda.stream(st):
+                    if imp:
+                        ic.decode_async(lv.shape[0])
+                    c.decode_async(mk, cd.shape[0])
 
-    def roundtrip_ok():
-        return all(bool(torch.equal(c.code_out[:cd.shape[0]], cd * mk)) and int(c.err[:cd.shape[0]].abs().sum().item()) == 0
-                   for c, cd, mk in zip(codecs, codes, masks))
+    def exact(cds, mks, lvs, imp=True):
+        ok = True
+        for c, ic, cd, mk, lv in zip(codecs, icodecs, cds, mks, lvs):
+            n = cd.shape[0]
+            if not n:
+                continue
+            ok = ok and bool(torch.equal(c.code_out[:n], cd * mk)) and int(c.err[:n].abs().sum().item()) == 0
+            if imp:
+                ok = ok and bool(torch.equal(ic.levels_out[:n], lv)) and int(ic.err[:n].abs().sum().item()) == 0
+        return ok
 
+    step = lambda: run(codes, masks, levels, True)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    # correctness of what is being timed: decode(encode(x)) == x on every rank, no coder faults
-    ok = roundtrip_ok()
-    for c in codecs:
-        c.profile(True)
-    dt = shard.timed(step, args.steps, dev)                   # barrier + sync both sides, MAX over ranks
-    prof = {"ec_ms": 0.0, "ec_launches": 0, "dc_ms": 0.0, "dc_launches": 0}
-    for c in codecs:
-        pr = c.profile_read()
-        for k in prof:
-            prof[k] += pr[k]
-        c.profile(False)
-    ok = ok and roundtrip_ok()
-    # the same kernels with the GPU to themselves: one sub-batch, one stream (per-launch durations above are stretched by
-    # the other streams' kernels sharing the CUs)
-    codecs[0].profile(True)
-    with torch.cuda.stream(streams[0]):
-        codecs[0].encode_async(codes[0], masks[0])
-        codecs[0].decode_async(masks[0], codes[0].shape[0])
-    torch.cuda.synchronize(dev)
-    iso = codecs[0].profile_read()
-    codecs[0].profile(False)
-    # extra pass, reported next to `value`: the same steps with the images' importance-map streams (32x64 maps, 49 levels,
-    # device-resident FusedImpCodec on the same streams) encoded and decoded as well -- both bitstreams of every image
-    with_imp = None
-    if not args.no_importance_pass:
-        from lic360_fused import FusedImpCodec
-        imp_layers = make_imp_params(1000 * SSIM + MODEL_IDX)
-        icodecs, levels, o = [], [], 0
-        for sz in sizes:
-            ic = FusedImpCodec(H // 2, W // 2, max_batch=sz, device=local)
-            ic.load_layers(imp_layers)
-            icodecs.append(ic)
-            levels.append(torch.from_numpy(level_np[o:o + sz]).to(dev))
-            o += sz
+    ok = exact(codes, masks, levels)
+    dt = shard.timed(step, args.steps, dev)                   # barrier + sync both sides, MAX over ranks; instrumentation off
+    ok = ok and exact(codes, masks, levels)
+    nbytes = np.concatenate([c.nbytes[:cd.shape[0]].cpu().numpy() for c, cd in zip(codecs, codes)])
+    inbytes = np.concatenate([c.nbytes[:cd.shape[0]].cpu().numpy() for c, cd in zip(icodecs, codes)])
+    img0 = (bytes(codecs[0].bytes[0, :int(nbytes[0])].cpu().numpy().tobytes()), bytes(icodecs[0].bytes[0, :int(inbytes[0])].cpu().numpy().tobytes()))
 
-        def step_full():
-            for c, ic, cd, mk, lv, st in zip(codecs, icodecs, codes, masks, levels, streams):
-                with torch.cuda.stream(st):
-                    ic.encode_async(lv)
-                    c.encode_async(cd, mk)
-            for c, ic, cd, mk, lv, st in zip(codecs, icodecs, codes, masks, levels, streams):
-                with torch.cuda.stream(st):
-                    ic.decode_async(lv.shape[0])
-                    c.decode_async(mk, cd.shape[0])
-
-        step_full()
-        dt_full = shard.timed(step_full, args.steps, dev)
-        ok_imp = all(bool(torch.equal(ic.levels_out[:lv.shape[0]], lv)) and int(ic.err[:lv.shape[0]].abs().sum().item()) == 0
-                     for ic, lv in zip(icodecs, levels))
-        with_imp = {"value": world * B * args.steps * PIXELS / dt_full / 1e6, "unit": "Mpixel/s", "ms_per_step": dt_full / args.steps * 1e3,
-                    "roundtrip_exact": shard.all_ok(ok_imp and roundtrip_ok(), dev),
-                    "mean_importance_bytes": float(np.mean([float(ic.nbytes[:lv.shape[0]].float().mean().item()) for ic, lv in zip(icodecs, levels)]))}
+    extras = {}
+    if not args.no_extras:
+        # the latent stream alone (98.6 % of the bytes, 95 % of the MACs): round 1's headline, kept for comparison
+        run(codes, masks, levels, False)
+        dt_lat = shard.timed(lambda: run(codes, masks, levels, False), args.steps, dev)
+        extras["latent_stream_only"] = {"value": world * B * args.steps * PIXELS / dt_lat / 1e6, "unit": "Mpixel/s", "ms_per_step": dt_lat / args.steps * 1e3}
+        # BASELINE.json configs[3]: 64 images, image i -> rank i mod N, through the same codecs and streams
+        mine = shard.shard_indices(64, rank, world)
+        c4, m4, l4 = synth_latents(64, seed0=640000)
+        per = [mine[i::ns] for i in range(ns)]
+        cd4 = [torch.from_numpy(c4[ix]).to(dev) if ix else torch.zeros((0, G, H, W), device=dev) for ix in per]
+        mk4 = [torch.from_numpy(m4[ix]).to(dev) if ix else torch.zeros((0, G, H, W), device=dev) for ix in per]
+        lv4 = [torch.from_numpy(l4[ix]).to(dev) if ix else torch.zeros((0, 1, H // 2, W // 2), device=dev) for ix in per]
+        run(cd4, mk4, lv4)
+        dt4 = shard.timed(lambda: run(cd4, mk4, lv4), 3, dev)
+        ok = ok and exact(cd4, mk4, lv4)
+        extras["config4"] = {"images": 64, "images_per_gpu": len(mine), "ms": dt4 / 3 * 1e3, "value": 64 * PIXELS / (dt4 / 3) / 1e6, "unit": "Mpixel/s",
+                             "scaling": "strong", "note": "BASELINE.json configs[3]: fixed list of 64 images, image i -> rank i mod N, both streams"}
     ok = shard.all_ok(ok, dev)
 
     if rank == 0:
-        images = world * B * args.steps
-        value = images * PIXELS / dt / 1e6
-        nbytes = np.concatenate([c.nbytes[:cd.shape[0]].cpu().numpy() for c, cd in zip(codecs, codes)])
-        # dominant kernel: hidden-layer masked conv, encode order vs decode order
-        ec_t, dc_t = prof["ec_ms"], prof["dc_ms"]
-        b0 = int(codes[0].shape[0])                        # images per launch (one sub-batch)
-        dom_dc = dc_t >= ec_t
-        if dom_dc:
-            name, tot_ms, launches = "k_cconv4v6<4, false, false> (decode order, hidden layers)", dc_t, prof["dc_launches"]
-            iso_ms = iso["dc_ms"] / max(iso["dc_launches"], 1)
-            bytes_per_launch = dc_hidden_bytes_per_launch(b0)
-        else:
-            name, tot_ms, launches = "k_cconv4v6<4, true, false> (encode order, hidden layers)", ec_t, prof["ec_launches"]
-            iso_ms = iso["ec_ms"] / max(iso["ec_launches"], 1)
-            bytes_per_launch = ec_hidden_bytes_per_launch(b0)
-        flops_per_launch = 2 * HIDDEN_GMAC * 1e9 * B * 10 * args.steps / max(launches, 1)   # all hidden launches of a step cover B images x 10 layers
-        avg_ms = tot_ms / max(launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        iso_gbs = bytes_per_launch / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
-        tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        iso_tf = flops_per_launch / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else 0.0
-        traffic = None
-        try:      # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["dominant_kernel"]
-            if dom_dc:
-                traffic = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
-        except Exception:
-            traffic = None
         out = {
             "metric": "ERP Mpixels/s enc+dec @512x1024 model-idx 3; bitstream bit-exact vs ref",
-            "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": world * B * args.steps * PIXELS / dt / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 512x1024 ERP latents per GPU (48x64x128 symbols + importance mask), "
-                                   "model-idx 3 --ssim seeded weights, latent entropy encode+decode (BASELINE.json configs[3] per-GPU share)" % B,
-                       "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok, "mean_bitstream_bytes": float(nbytes.mean()),
-                       "with_importance_stream": with_imp},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "algorithmic_flops_per_launch": flops_per_launch, "images_per_launch": b0,
-                         "avg_launch_ms": avg_ms, "launches": launches, "concurrent_streams": ns,
-                         "isolated": {"achieved": iso_tf, "frac": iso_tf / F32_MFMA_PEAK_TFLOPS, "avg_launch_ms": iso_ms,
-                                      "note": "same kernel, one sub-batch alone on the GPU (single stream); in the timed run "
-                                              "kernels of the other streams share the CUs and stretch each launch"},
-                         "hbm": {"algorithmic_bytes_per_launch": bytes_per_launch, "achieved": achieved, "isolated": iso_gbs,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "frac_isolated": iso_gbs / HBM_PEAK_GBS},
-                         "aggregate": {"achieved": 2 * 2 * NET_GMAC * 1e9 * B / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
-                                       "frac": 2 * 2 * NET_GMAC * 1e9 * B / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                                       "note": "algorithmic FLOPs of every conv layer of encode + decode of the step / wall time of the step "
-                                               "(all streams; includes the arithmetic-coder phases that are not hidden)"},
-                         "ec_hidden_ms_per_step": ec_t / args.steps, "dc_hidden_ms_per_step": dc_t / args.steps},
+            "config": {"workload": "batch of %d synthetic 512x1024 ERPs per GPU: quantised latent (48x64x128 symbols under its importance mask) AND "
+                                   "32x64 importance map of every image, model-idx 3 --ssim seeded weights, entropy encode + decode of both "
+                                   "bitstreams (BASELINE.json configs[3], per-GPU form)" % B,
+                       "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok,
+                       "bit_exact_against": "CPU oracle (arithmetic coder pinned to the reference's ArithmeticCoder.cpp; float kernels unpinnable without CUDA)",
+                       "mean_latent_bytes": float(nbytes.mean()), "mean_importance_bytes": float(inbytes.mean())},
         }
+        out["config"].update(extras)
+        out.update(instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B))
+        if world == 1 and not args.no_extras:
+            out["config"]["single_image"] = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], dev)
+            try:
+                import stream_ops_bench
+                rows = stream_ops_bench.measure(batches=(32,), device=local)
+                out["kernels"] += [{"kernel": r["op"], "bound": "hbm", "achieved": r["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": r["frac_of_hbm_peak"], "avg_launch_ms": r["us"] * 1e-3, "images_per_launch": 32} for r in rows]
+            except Exception as e:                                     # noqa: BLE001  (never lose the headline to a side table)
+                out["config"]["streaming_ops_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(layers)
+            out["cpu_baseline"] = cpu_baseline(layers, imp_layers, code_np[0:1], mask_np[0:1], level_np[0:1], img0[0], img0[1])
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def single_image(c, ic, code, mask, lv, st, dev):
+    """BASELINE.json configs[1] / [2]: one 512x1024 image alone on the GPU -- encode latency, decode latency (both streams)."""
+    import torch
+    res = {}
+    with torch.cuda.stream(st):
+        for name, fn in (("encode_ms", lambda: (ic.encode_async(lv[:1]), c.encode_async(code[:1], mask[:1]))),
+                         ("decode_ms", lambda: (ic.decode_async(1), c.decode_async(mask[:1], 1)))):
+            fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            res[name] = (time.perf_counter() - t0) / 3 * 1e3
+    res["roundtrip_exact"] = bool(torch.equal(c.code_out[:1], code[:1] * mask[:1]) and torch.equal(ic.levels_out[:1], lv[:1]))
+    res["value"] = PIXELS / ((res["encode_ms"] + res["decode_ms"]) * 1e-3) / 1e6
+    res["unit"] = "Mpixel/s"
+    res["note"] = "configs[1]/[2]: latency-bound (238 dependent planes x 14 launches, one serial coder chain)"
+    return res
+
+
+def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B):
+    """Per-kernel-class durations from HIP events on the launch stream: (a) one sub-batch ALONE on the GPU, (b) all streams."""
+    import torch
+    b0 = int(codes[0].shape[0])
+
+    def one_pass(k):
+        for i in k:
+            with torch.cuda.stream(streams[i]):
+                codecs[i].encode_async(codes[i], masks[i])
+        for i in k:
+            with torch.cuda.stream(streams[i]):
+                codecs[i].decode_async(masks[i], codes[i].shape[0])
+        torch.cuda.synchronize(dev)
+
+    codecs[0].profile(True)
+    one_pass([0])
+    iso = codecs[0].profile_read()
+    codecs[0].profile(False)
+    for c in codecs:
+        c.profile(True)
+    one_pass(range(len(codecs)))
+    conc = {}
+    for c in codecs:
+        for k, (ms, n) in c.profile_read().items():
+            a = conc.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+        c.profile(False)
+
+    rows = []
+    for cls, (ms, n) in iso.items():
+        if n == 0:
+            continue
+        row = {"kernel": cls, "launches": n, "avg_launch_ms": ms / n, "images_per_launch": b0, "total_ms": ms}
+        part = cls.split("_", 1)[1] if cls[:3] in ("ec_", "dc_") else None
+        if part in GMAC:
+            fl = 2 * GMAC[part] * 1e9 * b0                         # whole pass of this class over b0 images, one direction
+            row.update(bound="mfma", achieved=fl / (ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                       algorithmic_flops_per_launch=fl / n)
+        elif cls in ("enc_tables", "dec_tables"):
+            per_sym = 52.0 if cls == "enc_tables" else 72.0        # 9 floats of net output + symbol/mask in; (lo,hi) record or 7 entries + flag out
+            by = per_sym * NSYM * b0
+            row.update(bound="hbm", achieved=by / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic_bytes_per_launch=by / n)
+        else:                                                      # serial arithmetic-coder chains: one wave per image
+            row.update(bound="latency", achieved=ms * 1e6 / NSYM, peak=None, unit="ns per symbol of one image's serial chain")
+        row["frac"] = row["achieved"] / row["peak"] if row.get("peak") else None
+        if cls in conc and conc[cls][1]:
+            row["avg_launch_ms_concurrent"] = conc[cls][0] / conc[cls][1]
+        rows.append(row)
+    convs = [r for r in rows if r["bound"] == "mfma"]
+    dom = max(convs, key=lambda r: r["total_ms"])
+    traffic = None
+    try:      # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, profiles/)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))[dom["kernel"]]
+        traffic = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
+    except Exception:                                              # noqa: BLE001
+        traffic = None
+    conv_ms = sum(r["total_ms"] for r in convs)
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["frac"], "traffic": traffic, "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
+                "images_per_launch": b0, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
+                "how": "one sub-batch alone on the GPU, one stream, HIP events around every launch on the launch stream (instrumented pass, "
+                       "outside the timed region)",
+                "concurrent": {"avg_launch_ms": dom.get("avg_launch_ms_concurrent"), "streams": len(codecs),
+                               "note": "same kernel while the other streams' kernels share the CUs (the timed region's regime)"},
+                "all_conv_layers_isolated": {"achieved": 2 * 2 * NET_GMAC * 1e9 * b0 / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                             "frac": 2 * 2 * NET_GMAC * 1e9 * b0 / (conv_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
+                "whole_step": {"achieved": 2 * 2 * (NET_GMAC + IMP_GMAC) * 1e9 * B / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
+                               "frac": 2 * 2 * (NET_GMAC + IMP_GMAC) * 1e9 * B / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                               "note": "algorithmic FLOPs of every conv layer (both nets, both directions) / wall time of the timed step"}}
+    return {"roofline": roofline, "kernels": rows}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # supervisor: no HIP call in this process (device_count() does not initialise the runtime on this image)
+        import lic360_shard as shard
+        if not args.dry_run:
+            import torch
+            if torch.cuda.device_count() < args.gpus:
+                sys.stderr.write("bench.py: --gpus %d but only %d HIP devices are visible\n" % (args.gpus, torch.cuda.device_count()))
+                return 2
+        return shard.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    return dry_run(args) if args.dry_run else run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -207,10 +207,12 @@ int lic360_devcoder_encode(void *stream, const int *tables, int ncode, const int
 int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const float *mask, long n, int chunk,
                            const uint8_t *bytes, long cap, const int *nbytes, float *out, int *err);
 
-/* timing hooks for bench.py: HIP events around every hidden-layer conv launch (encode-order / decode-order),
- * recorded on the caller's stream; read() returns the summed elapsed ms + launch counts and resets */
+/* timing hooks for bench.py's instrumented pass: HIP events around every launch of each kernel class of the codec
+ * (classes() names them, comma separated: first / hidden / last conv layers in both orders, table builds, coder kernels),
+ * recorded on the caller's stream; read() fills ms[k] / launches[k] per class (n >= number of classes) and resets */
 int lic360_codec_profile_enable(lic360_codec *codec, int on);
-int lic360_codec_profile_read(lic360_codec *codec, double *ec_ms, long *ec_launches, double *dc_ms, long *dc_launches);
+const char *lic360_codec_profile_classes(void);
+int lic360_codec_profile_read(lic360_codec *codec, int n, double *ms, long *launches);
 
 #ifdef __cplusplus
 }

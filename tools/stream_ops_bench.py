@@ -1,12 +1,14 @@
 """Achieved HBM GB/s of the streaming ops of the path (algorithmic bytes / time against 8 TB/s), at the
 512x1024 single-image sizes of test/model_zoo.py and at a 32-image batch.  Writes one JSON document to stdout."""
-import json, sys
-sys.path.insert(0, "360-image-compression_amd")
-import torch
-import lic360
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "360-image-compression_amd"))
+import torch  # noqa: E402
+import lic360  # noqa: E402
 
 PEAK = 8000.0
-dev = "cuda:0"
 
 
 def timed(fn, reps=50):
@@ -22,44 +24,50 @@ def timed(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-rows = []
+def measure(batches=(1, 32), device=0):
+    """-> rows of {op, images, algorithmic_MB, us, GBps, frac_of_hbm_peak}; called by bench.py (batch 32) and by __main__"""
+    dev = "cuda:%d" % device
+    rows = []
+
+    def add(name, n, nbytes, fn):
+        t = timed(fn)
+        rows.append({"op": name, "images": n, "algorithmic_MB": nbytes / 1e6, "us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / PEAK})
+
+    for n in batches:
+        g = torch.Generator(device=dev).manual_seed(1)
+        # ERP apron refresh on the largest feature map (in place: only the 2-cell apron is read and written)
+        x = torch.randn((n, 192, 260, 516), device=dev, generator=g)
+        apron = n * 192 * (260 * 516 - 256 * 512) * 4
+        pad = lic360.SpherePadOp(2, True, device, False)
+        add("sphere_pad (in place, 260x516)", n, 2 * apron, lambda: pad.forward(x))
+        trim = lic360.SphereTrimOp(2, device, False)
+        add("sphere_trim (in place, 260x516)", n, apron, lambda: trim.forward(x))
+        del x
+        # out-of-place pad of the decoder's first map
+        y = torch.randn((n, 192, 32, 64), device=dev, generator=g)
+        pad2 = lic360.SpherePadOp(2, False, device, False)
+        add("sphere_pad (36x68 from 32x64)", n, n * 192 * (32 * 64 + 36 * 68) * 4, lambda: pad2.forward(y))
+        # pixel (un)shuffle, quantiser, dequantiser on the latent
+        dtow = lic360.DtowOp(2, True, device, False)
+        add("dtow [192,32,64]->[48,64,128]", n, 2 * y.numel() * 4, lambda: dtow.forward(y))
+        wb = torch.randn((192, 8), device=dev, generator=g).sort(dim=1).values.contiguous()
+        cnt = torch.zeros((192, 8), device=dev)
+        q = lic360.QuantOp(192, 8, 0.9, 100, 2, 0.1, device, False)
+        add("quant (value + index out)", n, 3 * y.numel() * 4, lambda: q.forward(y, wb, cnt, False))
+        idx = torch.randint(0, 8, y.shape, device=dev, generator=g).float()
+        msk = (torch.rand(y.shape, device=dev, generator=g) > 0.3).float()
+        dq = lic360.DquantOp(192, 8, device, False)
+        add("dquant", n, 3 * y.numel() * 4, lambda: dq.forward(idx, msk, wb))
+        # drop-in GMM table op: M symbols x (9 floats in, 9 floats out)
+        m = n * 8192
+        w3, d3, m3 = (torch.randn((m, 3, 1, 1), device=dev, generator=g) for _ in range(3))
+        tab = lic360.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, device, False)
+        tn = torch.tensor([m], dtype=torch.int32)
+        add("entropy_gmm_table (8192 symbols per image)", n, m * 72, lambda: tab.forward(w3, d3, m3, tn))      # (softmax / sigma floor are written back in place, as in the reference)
+    return rows
 
 
-def add(name, n, nbytes, fn):
-    t = timed(fn)
-    rows.append({"op": name, "images": n, "algorithmic_MB": nbytes / 1e6, "us": t * 1e6, "GBps": nbytes / t / 1e9, "frac_of_hbm_peak": nbytes / t / 1e9 / PEAK})
-
-
-for n in (1, 32):
-    g = torch.Generator(device=dev).manual_seed(1)
-    # ERP apron refresh on the largest feature map (in place: only the 2-cell apron is read and written)
-    x = torch.randn((n, 192, 260, 516), device=dev, generator=g)
-    apron = n * 192 * (260 * 516 - 256 * 512) * 4
-    pad = lic360.SpherePadOp(2, True, 0, False)
-    add("sphere_pad (in place, 260x516)", n, 2 * apron, lambda: pad.forward(x))
-    trim = lic360.SphereTrimOp(2, 0, False)
-    add("sphere_trim (in place, 260x516)", n, apron, lambda: trim.forward(x))
-    del x
-    # out-of-place pad of the decoder's first map
-    y = torch.randn((n, 192, 32, 64), device=dev, generator=g)
-    pad2 = lic360.SpherePadOp(2, False, 0, False)
-    add("sphere_pad (36x68 from 32x64)", n, n * 192 * (32 * 64 + 36 * 68) * 4, lambda: pad2.forward(y))
-    # pixel (un)shuffle, quantiser, dequantiser on the latent
-    dtow = lic360.DtowOp(2, True, 0, False)
-    add("dtow [192,32,64]->[48,64,128]", n, 2 * y.numel() * 4, lambda: dtow.forward(y))
-    wb = torch.randn((192, 8), device=dev, generator=g).sort(dim=1).values.contiguous()
-    cnt = torch.zeros((192, 8), device=dev)
-    q = lic360.QuantOp(192, 8, 0.9, 100, 2, 0.1, 0, False)
-    add("quant (value + index out)", n, 3 * y.numel() * 4, lambda: q.forward(y, wb, cnt, False))
-    idx = torch.randint(0, 8, y.shape, device=dev, generator=g).float()
-    msk = (torch.rand(y.shape, device=dev, generator=g) > 0.3).float()
-    dq = lic360.DquantOp(192, 8, 0, False)
-    add("dquant", n, 3 * y.numel() * 4, lambda: dq.forward(idx, msk, wb))
-    # drop-in GMM table op: M symbols x (9 floats in, 9 floats out)
-    m = n * 8192
-    w3, d3, m3 = (torch.randn((m, 3, 1, 1), device=dev, generator=g) for _ in range(3))
-    tab = lic360.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, 0, False)
-    tn = torch.tensor([m], dtype=torch.int32)
-    add("entropy_gmm_table (8192 symbols per image)", n, m * 72, lambda: tab.forward(w3, d3, m3, tn))      # (softmax / sigma floor are written back in place, as in the reference)
-print(json.dumps({"peak_GBps": PEAK, "note": "torch.cuda.Event timing of 50 back-to-back calls through the lic360 shim (includes its per-call Python/ctypes "
+if __name__ == "__main__":
+    rows = measure()
+    print(json.dumps({"peak_GBps": PEAK, "note": "torch.cuda.Event timing of 50 back-to-back calls through the lic360 shim (includes its per-call Python/ctypes "
                   "overhead; single-image tensors are a few MB, so those rows are launch-latency bound)", "rows": rows}, indent=1))
