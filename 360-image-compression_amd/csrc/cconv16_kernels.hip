@@ -1,0 +1,409 @@
+// cconv16_kernels.hip -- ENCODE-order group-causal masked convolution of the latent entropy nets (A9 for the shapes
+// test/lic360_demo.py:104-112 uses: ngroup groups, cin in {1,4}, cout in {3,4}) on v_mfma_f32_16x16x4_f32.
+//
+// Arithmetic contract (extension/cconv_ec_cuda.cu:268-315): per output scalar 128 virtual lanes, lane
+// (gid, kh, kw) runs ONE fmaf chain over ti = gid, gid+cin, ... (= input groups tc = 0, 1, ...), then the fixed tree
+// p[i]+p[i+64]; +32; ...; +1.  v_mfma_f32_16x16x4_f32 is, bit for bit, a k-ordered fmaf chain of 4 terms
+// (D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C))))), so with K = four CONSECUTIVE input groups of one lane's chain an
+// MFMA advances 256 chains by four terms each, in order -- at the full fp32 matrix rate (the 4x4x1 form used in decode
+// order tops out at 74 % of it and blocks the VALU while it issues).
+//
+// Mapping ("leaf-resident" like cconv4_kernels.hip: every chain of every output owns an accumulator until the tree):
+//   * MFMA rows  = 16 outputs that read the SAME input at the SAME tap: 4 consecutive groups g0..g0+3 x their 4 output
+//     channels.  In encode order all groups are evaluated at the same positions, so the B operand is shared exactly; the
+//     groups' chains differ in length by one each (L = g+4+hidden-kh-kw) -- the packed A operand carries zero weights
+//     past a chain's end (fma(0, x, acc) == acc).
+//   * MFMA cols  = 16 consecutive positions of one image row.
+//   * K          = input groups tc0..tc0+3 of the chain's channel gid (cin = 4), or tc0+4sq..+3 (cin = 1).
+//   * a workgroup (8 waves, two per SIMD) owns a 4-row x 16-column tile of one (sample, group block): wave (ps, c) keeps the
+//     chains of lane class c (lanes = c mod 4: 25 chains for cin = 4, 7/6 for cin = 1) of rows 2ps, 2ps+1 resident: 2 x 25
+//     accumulators of 4 registers = 200 of the wave's 256.  Lanes of equal index mod 4 stay together until the last two
+//     tree levels, so each wave reduces in registers and one tile per wave and row crosses LDS for the final (F0+F2)+(F1+F3).
+//     (One wave per SIMD with all four rows -- 400 accumulator registers -- was tried first: hipcc cannot keep more
+//     accumulators than one half of the unified register file holds without copying or spilling them around every MFMA.)
+//   * a STEP = 16 input channel planes (cin = 4: four input groups; cin = 1: sixteen): their 8 x 20 halo tiles (10 KB) and
+//     the step's packed weights (4 classes x 28 slots x 64 lanes, 28 KB) go to a double-buffered LDS image by LDS-DMA
+//     (global_load_lds_dwordx4, 5 per wave and step, no staging registers: the accumulators leave none to spare)
+//     while the previous step computes; one barrier per step; per wave and step 25 weight reads + 50 operand reads
+//     (ds_read_b32, immediate offsets only) feed 50 MFMAs of 32 cycles.
+//   * workgroups are persistent; tasks = (sample, 4 consecutive tiles, group block), group block fastest, pulled from a
+//     per-XCD counter so that the workgroups of an XCD sweep one input region together (it stays in that XCD's L2) and the
+//     group blocks' 6x different lengths balance; the staging pipeline runs across tile and task boundaries.
+// Activations: zero-haloed NCHW planes [n][c][hp][wp], cell (r, c) at [(r+2)*wp + c+2] (lic360_ec16_layout); rows / columns
+// beyond the image are never written and stay zero, so no load is conditional.
+#include "common.h"
+#include "conv_plan.h"
+#include "cconv_tree.h"
+
+#define C16_SLOTS 28                       // weight slots per lane class and step (cin = 4: 25 taps; cin = 1: 4 sub-quads x 7 taps)
+#define C16_TH 4                           // tile rows
+#define C16_TW 16                          // tile columns = MFMA columns
+#define C16_NT 2                           // tile rows per wave
+#define C16_HR (C16_TH + 4)
+#define C16_HC (C16_TW + 4)
+#define C16_PLANE 164                      // floats per staged plane: 8 x 20 + one pad quad, so that 4 planes = 16 banks (mod 32)
+#define C16_WFL (4 * C16_SLOTS * 64)       // floats of packed weights per step (28 KB)
+#define C16_XWIN 11                        // 1 KB LDS-DMA windows of x per step: 11 x 64 quads >= 16 planes x 41 quads
+#define C16_WWIN (C16_WFL / 256)           // ... of weights (28)
+#define C16_XFL (C16_XWIN * 256)
+#define C16_NDMA 5                         // DMAs per wave and step: 8 x 5 = 40 windows = 11 + 28 + 1 dump
+#define C16_BUF (C16_XFL + C16_WFL + 256)  // floats per LDS buffer: x | weights | dump window
+#define C16_THREADS 512
+#define C16_COMB (C16_TH * 4 * 4 * 64)     // tile rows x classes x registers x lanes
+#define C16_TPT 4                          // tiles per task
+
+static inline bool conv16_ok(const lic360_conv_plan *p) {
+    return p->ksz == 5 && (p->cin == 1 || p->cin == 4) && p->cout >= 1 && p->cout <= 4 && p->ngroup >= 1 && p->ngroup <= 256;
+}
+static inline int conv16_tcs(int cin) { return cin == 4 ? 4 : 16; }                       // input groups per step
+static inline int conv16_nsteps_max(const lic360_conv_plan *p) { return (p->ngroup + conv16_tcs(p->cin) - 1) / conv16_tcs(p->cin); }
+static inline int conv16_ngb(const lic360_conv_plan *p) { return (p->ngroup + 3) / 4; }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// packed16[net][gb][step][class c][slot][lane l]:  lane l = 16 k + i carries A[row i][k] of the slot's MFMA:
+//   row i = 4 q + r  (group g0 + q, output channel r),  k = input group offset inside the quad;
+//   cin = 4: slot = tap, gid = (c - tap) mod 4, input channel (tc0 + k) * 4 + gid;
+//   cin = 1: slot = 7 sq + j, tap = c + 4 j, input channel tc0 + 4 sq + k.
+// Zero where the chain has ended (tc >= L = g + 4 + hidden - kh - kw, capped at ngroup), for r >= cout, g >= ngroup, unused slots.
+__global__ void k_conv16_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int G, int cin, int cout, int hidden, int NS) {
+    const int n_gb = (G + 3) / 4, tcs = cin == 4 ? 4 : 16;
+    const long per_net = (long)n_gb * NS * C16_WFL, total = per_net * nb;
+    const int C = G * cin, nout = G * cout;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(e & 63);
+        long t = e >> 6;
+        const int slot = (int)(t % C16_SLOTS); t /= C16_SLOTS;
+        const int c = (int)(t & 3); t >>= 2;
+        const int step = (int)(t % NS); t /= NS;
+        const int gb = (int)(t % n_gb), b = (int)(t / n_gb);
+        const int i = l & 15, k = l >> 4, q = i >> 2, r = i & 3, g = gb * 4 + q;
+        int tap, tc, ci;
+        if (cin == 4) { tap = slot; tc = step * tcs + k; ci = tc * 4 + ((c - tap) & 3); }
+        else { const int sq = slot / 7, j = slot % 7; tap = c + 4 * j; tc = step * tcs + 4 * sq + k; ci = tc; }
+        float v = 0.0f;
+        if (tap < 25 && slot < (cin == 4 ? 25 : 28) && g < G && r < cout) {
+            const int kh = tap / 5, kw = tap % 5;
+            int L = g + 4 - kh - kw + hidden;                               // extension/cconv_ec_cuda.cu:288-290
+            if (L > G) L = G;
+            if (tc < L) v = weight[(((long)b * nout + g * cout + r) * C + ci) * 25 + tap];
+        }
+        packed[e] = v;
+    }
+}
+
+LIC360_API int lic360_conv16_supported(const lic360_conv_plan *p) { return p && conv16_ok(p) ? 1 : 0; }
+LIC360_API long lic360_conv16_packed_floats(const lic360_conv_plan *p) {
+    return p && conv16_ok(p) ? (long)conv16_ngb(p) * conv16_nsteps_max(p) * C16_WFL : 0;
+}
+LIC360_API int lic360_conv16_pack(void *stream, const lic360_conv_plan *p, const float *weight, int nb, float *packed) {
+    ARG_CHECK(p && conv16_ok(p) && weight && packed && nb > 0);
+    const long total = lic360_conv16_packed_floats(p) * nb;
+    hipLaunchKernelGGL(k_conv16_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, nb, p->ngroup, p->cin,
+                       p->cout, p->constrain == 5 ? 0 : 1, conv16_nsteps_max(p));
+    LAUNCH_CHECK();
+    return 0;
+}
+LIC360_API int lic360_ec16_layout(int h, int w, int *hp, int *wp) {
+    ARG_CHECK(hp && wp && h > 0 && w > 0);
+    *hp = (h + C16_TH - 1) / C16_TH * C16_TH + 4;
+    *wp = (w + C16_TW - 1) / C16_TW * C16_TW + 4;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+// LDS-DMA through inline asm (the idiom of cconv4v3_dc.inc): destination = M0 + lane * 16; the compiler does not see these
+// VMEM operations, completion is enforced by hand (C16_WAIT0 before the barrier that publishes the buffer).
+#define C16_WAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ __forceinline__ void c16_dma_x4(const float *src, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned c16_lds_addr(const float *p) {
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const float *)p;
+}
+
+struct C16Args {
+    const float *x, *packed, *bias, *act, *residual;
+    float *out;
+    int *ctr;                                  // 8 task counters (one per XCD), zeroed by the host before the launch
+    int G, cout, hidden, H, W, hp, wp, npb, x_mod, N;
+    int n_gb, ntx, ntiles, n_chunks, NS;
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// taps of the three tap-diagonal ranges (d = kh + kw <= 3, 4..5, 6..8), in tap order
+__host__ __device__ constexpr int c16_range_count(int R) { return R == 0 ? 10 : (R == 1 ? 9 : 6); }
+__host__ __device__ constexpr int c16_range_tap(int R, int i) {
+    int n = 0;
+    for (int tap = 0; tap < 25; ++tap) {
+        const int d = tap / 5 + tap % 5, r = d <= 3 ? 0 : (d <= 5 ? 1 : 2);
+        if (r == R) { if (n == i) return tap; ++n; }
+    }
+    return -1;
+}
+// cin = 4, one range of one step: per chain 1 weight read + 2 operand reads + 2 MFMAs, software-pipelined one chain deep (the
+// reads of chain i+1 are issued before the MFMAs of chain i); sched_barriers pin that order -- left alone, the scheduler hoists
+// every read of the range above the first MFMA and spills the accumulators.
+template <int CLS, int R>
+__device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, const float *ws) {
+    constexpr int N = c16_range_count(R);
+    float av[2], bv[2][C16_NT];
+    auto load = [&](auto tt, int into) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tt)::value, kh = tap / 5, kw = tap % 5, gid = (CLS - tap) & 3;
+        av[into] = ws[tap * 64];
+#pragma unroll
+        for (int t = 0; t < C16_NT; ++t) bv[into][t] = xs[gid * C16_PLANE + (kh + t) * C16_HC + kw];
+    };
+    load(IC<c16_range_tap(R, 0)>{}, 0);
+    static_for<N>([&](auto ii) {
+        constexpr int i = decltype(ii)::value, tap = c16_range_tap(R, i), cur = i & 1;
+        if constexpr (i + 1 < N) load(IC<c16_range_tap(R, i + 1)>{}, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < C16_NT; ++t) acc[t][tap] = mfma16(av[cur], bv[cur][t], acc[t][tap]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <int CIN, int CLS, int PS>
+__device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *comb, int *tq, const int tid, const int lane) {
+    constexpr int NA = NAcc<CIN>::value;
+    constexpr int TCS = CIN == 4 ? 4 : 16;                                  // input groups per step
+    constexpr int WAVE = PS * 4 + CLS;
+    const int G = a.G, C = G * CIN, nout = G * a.cout;
+    const long PL = (long)a.hp * a.wp;
+    const int xcd = blockIdx.x & 7;
+    const int ns_x = (a.N - xcd + 7) >> 3;                                  // samples of this XCD: n = xcd + 8 m
+    const int n_my = ns_x * a.n_chunks * a.n_gb;
+    // ---- task queue: thread 0 pulls task numbers three tasks ahead of the compute cursor into an 8-slot LDS ring
+    // (the issue cursor reads task c + 1 while the compute cursor is still in task c - 1, and a barrier must lie between a
+    // pull and its first read)
+    auto pull = [&](int k) __attribute__((always_inline)) { if (tid == 0) tq[k & 7] = atomicAdd(a.ctr + xcd, 1); };
+    auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]); };
+    // task u -> sample n, first tile, group block (group block fastest: the workgroups of an XCD share the input region)
+    auto decode = [&](int u, int &n, int &tile0, int &gb) __attribute__((always_inline)) {
+        gb = a.n_gb - 1 - u % a.n_gb;
+        const int v = u / a.n_gb;
+        tile0 = (v % a.n_chunks) * C16_TPT;
+        n = xcd + 8 * (v / a.n_chunks);
+    };
+    auto steps_of = [&](int gb) __attribute__((always_inline)) {
+        int gl = gb * 4 + 3;
+        if (gl > G - 1) gl = G - 1;
+        int L = gl + 4 + a.hidden;
+        if (L > G) L = G;
+        return (L + TCS - 1) / TCS;
+    };
+    pull(0);
+    pull(1);
+    pull(2);
+    pull(3);
+    __syncthreads();
+    // ---- LDS-DMA windows of this wave: window j = WAVE + 8 m (m < 5) of the step image [11 x | 28 weights | 1 dump]; lane l
+    // of an x window moves quad e = 64 j + l of [16 slots][41 quads] (quad 40 of a plane is padding, quads >= 656 are slack:
+    // both re-fetch a valid quad); a weight window moves 1 KB of the step's packed weights
+    constexpr int QPR = C16_HC / 4, QPP = C16_PLANE / 4;                    // quads per row / per plane incl. pad (5, 41)
+    static_assert(C16_XWIN * 64 >= 16 * QPP && C16_XWIN + C16_WWIN + 1 == 8 * C16_NDMA, "DMA windows cover the step image");
+    constexpr int NXD = (C16_XWIN - WAVE + 7) / 8;                          // x windows of this wave (1 or 2)
+    int xpl[NXD], xg[NXD];
+#pragma unroll
+    for (int m = 0; m < NXD; ++m) {
+        int e = (WAVE + 8 * m) * 64 + lane;
+        if (e >= 16 * QPP) e = 0;
+        const int slot = e / QPP;
+        int rem = e - slot * QPP;
+        if (rem >= C16_HR * QPR) rem = C16_HR * QPR - 1;
+        const int row = rem / QPR, cq = rem - row * QPR;
+        xpl[m] = CIN == 4 ? slot : ((slot & 3) * 4 + (slot >> 2));          // cin = 1: slot 4 k + sq holds channel tc0 + 4 sq + k
+        xg[m] = row * a.wp + cq * 4;
+    }
+    const unsigned lds_base = c16_lds_addr(lds);
+    // ---- issue cursor
+    int iq = 0, itile = 0, istep = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;
+    bool ivalid = false;
+    const float *ixb = a.x, *iwb = a.packed;                                // x of (sample, tile), weights of (net, group block)
+    auto issue_task = [&]() __attribute__((always_inline)) {
+        const int u = task(iq);
+        ivalid = u < n_my;
+        if (ivalid) {
+            decode(u, i_n, i_tile0, i_gb);
+            i_nsteps = steps_of(i_gb);
+            iwb = a.packed + ((long)(i_n / a.npb) * a.n_gb + i_gb) * a.NS * C16_WFL;
+        }
+    };
+    auto issue_tile = [&]() __attribute__((always_inline)) {
+        const int T = i_tile0 + itile, ty = T / a.ntx, tx = T - ty * a.ntx;
+        ixb = a.x + (long)(i_n % a.x_mod) * C * PL + (long)(ty * C16_TH) * a.wp + tx * C16_TW;
+    };
+    // LDS-DMA of the issue cursor's step into buffer `buf`, then advance the cursor (an exhausted cursor keeps re-reading its
+    // last addresses: every DMA stays unconditional and inside the tensors, 5 per wave and step)
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        const int ch0 = istep * (TCS * CIN);
+        const unsigned lb = lds_base + (unsigned)buf * (C16_BUF * 4);
+        const float *wsrc = iwb + (long)istep * C16_WFL + lane * 4;
+        static_for<C16_NDMA>([&](auto mm) {
+            constexpr int m = decltype(mm)::value, j = WAVE + 8 * m;
+            if constexpr (j < C16_XWIN) {
+                int c = ch0 + xpl[m];
+                if (c > C - 1) c = C - 1;                                   // planes past the last channel only meet zero weights
+                c16_dma_x4(ixb + (long)c * PL + xg[m], lb + j * 1024);
+            } else if constexpr (j < C16_XWIN + C16_WWIN) c16_dma_x4(wsrc + (j - C16_XWIN) * 256, lb + j * 1024);
+            else c16_dma_x4(wsrc, lb + j * 1024);                           // the 40th window: dump
+        });
+        if (ivalid) {
+            if (++istep == i_nsteps) {
+                istep = 0;
+                ++itile;
+                if (itile == C16_TPT || i_tile0 + itile >= a.ntiles) {
+                    itile = 0;
+                    ++iq;
+                    issue_task();
+                }
+                if (ivalid) issue_tile();
+                else { istep = i_nsteps - 1; }                               // idle: stay on the last step
+            }
+        }
+    };
+    issue_task();
+    if (!ivalid) return;                                                    // uniform: the whole workgroup has no task
+    issue_tile();
+    issue(0);
+    // ---- compute cursor
+    int cq = 0, ctile = 0, cstep = 0, c_nsteps, c_tile0, c_n, c_gb;
+    decode(task(0), c_n, c_tile0, c_gb);
+    c_nsteps = steps_of(c_gb);
+    f32x4 acc[C16_NT][NA];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < C16_NT; ++t)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
+    // operand addresses: lane (k = l >> 4, j = l & 15) reads plane slot 4 k + {gid | sq}, row 2 PS + t + kh, column j + kw
+    const int xlane = (lane >> 4) * 4 * C16_PLANE + (C16_NT * PS) * C16_HC + (lane & 15);
+    const int wlane = C16_XFL + CLS * C16_SLOTS * 64 + lane;
+    C16_WAIT0();
+    __syncthreads();
+    // (comb is double-buffered by tile parity: with one-step tiles the next tile's partial sums are written before the
+    // barrier that would separate them from this tile's reads)
+    int s = 0, ntile = 0;
+    bool done = false;
+    do {
+        const float *xs = lds + (s & 1) * C16_BUF + xlane, *ws = lds + (s & 1) * C16_BUF + wlane;
+        issue((s + 1) & 1);                                                 // next step's DMAs fly while this step computes
+        const int g0 = c_gb * 4, dl = g0 + 7 + a.hidden - cstep * TCS;      // tap diagonals d >= dl carry only zero weights
+        if constexpr (CIN == 4) {
+            // chains in three ranges of tap diagonals (d <= 3, 4..5, 6..8): the later ranges die first as tc grows
+            c16_range4<CLS, 0>(acc, xs, ws);
+            if (dl > 4) c16_range4<CLS, 1>(acc, xs, ws);
+            if (dl > 6) c16_range4<CLS, 2>(acc, xs, ws);
+        } else {
+            static_for<4>([&](auto ss) {
+                constexpr int sq = decltype(ss)::value;
+                const int dls = dl - 4 * sq;
+                static_for<NA>([&](auto ii) {
+                    constexpr int j = decltype(ii)::value, tap = CLS + 4 * j, kh = tap / 5, kw = tap % 5, d = kh + kw;
+                    if constexpr (tap < 25) {
+                        if (d < dls) {
+                            const float av = ws[(sq * 7 + j) * 64];
+                            float bv[C16_NT];
+#pragma unroll
+                            for (int t = 0; t < C16_NT; ++t) bv[t] = xs[sq * C16_PLANE + (kh + t) * C16_HC + kw];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int t = 0; t < C16_NT; ++t) acc[t][j] = mfma16(av, bv[t], acc[t][j]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                });
+            });
+        }
+        const bool last = cstep + 1 == c_nsteps;
+        if (last) {
+#pragma unroll
+            for (int t = 0; t < C16_NT; ++t) {
+                const f32x4 part = Tree4<CIN, CLS, 4>::eval(acc[t]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) comb[(ntile & 1) * C16_COMB + (((PS * C16_NT + t) * 4 + CLS) * 4 + r) * 64 + lane] = part[r];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
+            }
+        }
+        C16_WAIT0();                                                        // own DMAs of the next step have landed
+        __syncthreads();
+        if (last) {
+            // wave w finishes tile row w >> 1, output channels 2 (w & 1), 2 (w & 1) + 1 of the four groups: (F0 + F2) + (F1 + F3)
+            const int T = c_tile0 + ctile, ty = T / a.ntx, tx = T - ty * a.ntx;
+            constexpr int trow = WAVE >> 1;
+            const int q = lane >> 4, j = lane & 15;
+            const int y = ty * C16_TH + trow, x = tx * C16_TW + j, g = c_gb * 4 + q;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                constexpr int rbase = 2 * (WAVE & 1);
+                const int r = rbase + rr;
+                const float *cb = comb + (ntile & 1) * C16_COMB + ((trow * 4) * 4 + r) * 64 + lane;
+                const float f0 = cb[0], f1 = cb[4 * 64], f2 = cb[8 * 64], f3 = cb[12 * 64];
+                if (g < G && r < a.cout && y < a.H && x < a.W) {
+                    const int o = g * a.cout + r, bid = (c_n / a.npb) * nout + o;
+                    float sv = ((f0 + f2) + (f1 + f3)) + a.bias[bid];
+                    if (a.act) sv = sv > 0 ? sv : sv * a.act[bid];            // cconv_ec_cuda.cu:311-312
+                    const long oi = ((long)c_n * nout + o) * PL + (long)(y + 2) * a.wp + x + 2;
+                    if (a.residual) sv = sv + a.residual[oi];
+                    a.out[oi] = sv;
+                }
+            }
+            cstep = 0;
+            ++ntile;
+            ++ctile;
+            if (ctile == C16_TPT || c_tile0 + ctile >= a.ntiles) {
+                ctile = 0;
+                ++cq;
+                pull(cq + 3);                                               // first read two iterations (barriers) later
+                const int u = task(cq);
+                if (u < n_my) { decode(u, c_n, c_tile0, c_gb); c_nsteps = steps_of(c_gb); }
+                else done = true;
+            }
+        } else ++cstep;
+        ++s;
+    } while (!done);
+    C16_WAIT0();                                                            // no DMA may outlive the workgroup's LDS
+}
+
+template <int CIN>
+__global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
+    __shared__ float lds[2 * C16_BUF];
+    __shared__ float comb[2 * C16_COMB];
+    __shared__ int tq[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    switch (wave) {
+        case 0: c16_body<CIN, 0, 0>(a, lds, comb, tq, tid, lane); break;
+        case 1: c16_body<CIN, 1, 0>(a, lds, comb, tq, tid, lane); break;
+        case 2: c16_body<CIN, 2, 0>(a, lds, comb, tq, tid, lane); break;
+        case 3: c16_body<CIN, 3, 0>(a, lds, comb, tq, tid, lane); break;
+        case 4: c16_body<CIN, 0, 1>(a, lds, comb, tq, tid, lane); break;
+        case 5: c16_body<CIN, 1, 1>(a, lds, comb, tq, tid, lane); break;
+        case 6: c16_body<CIN, 2, 1>(a, lds, comb, tq, tid, lane); break;
+        default: c16_body<CIN, 3, 1>(a, lds, comb, tq, tid, lane); break;
+    }
+}
+
+// x / residual / out: [n][C | nout][hp][wp] zero-haloed planes (lic360_ec16_layout).  ctr: 8 ints of device scratch.
+LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                                 const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr) {
+    ARG_CHECK(p && conv16_ok(p) && x && packed16 && bias && out && ctr && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
+    C16Args a;
+    a.x = x; a.packed = packed16; a.bias = bias; a.act = act; a.residual = residual; a.out = out; a.ctr = ctr;
+    a.G = p->ngroup; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w; a.npb = n / nb; a.x_mod = x_mod; a.N = n;
+    if (lic360_ec16_layout(h, w, &a.hp, &a.wp)) return 2;
+    a.n_gb = conv16_ngb(p);
+    a.ntx = (w + C16_TW - 1) / C16_TW;
+    a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
+    a.n_chunks = (a.ntiles + C16_TPT - 1) / C16_TPT;
+    a.NS = conv16_nsteps_max(p);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));
+    if (p->cin == 4) hipLaunchKernelGGL(k_cconv16<4>, dim3(256), dim3(C16_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_cconv16<1>, dim3(256), dim3(C16_THREADS), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}

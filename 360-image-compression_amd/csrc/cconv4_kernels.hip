@@ -29,7 +29,7 @@
 #include "common.h"
 #include "conv_plan.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "cconv_tree.h"
 
 #define C4_COLS 68                       // 64 positions + 2*2 halo
 #define C4_WSLOTS 128                    // weight slots per step (>= 25*cin), 4 floats each
@@ -73,42 +73,6 @@ LIC360_API int lic360_conv4_pack(void *stream, const lic360_conv_plan *p, const 
                        p->cout, p->constrain == 5 ? 0 : 1);
     LAUNCH_CHECK();
     return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// the reference's reduction tree on registers: F(i, 128) = p[i];  F(i, s) = F(i, 2s) + F(i + s, 2s);  result F(0, 1)
-// (p[i] + p[i+64] first, ..., + p[i+1] last; cconv_ec_cuda.cu:299-309).  A wave of class c evaluates F(c, 4).
-// Lane i of class c = i%4 lives in accumulator i%25 (cin = 4) or i/4 (cin = 1).
-template <int CIN, int I, int S>
-struct Tree4 {
-    static constexpr bool live = Tree4<CIN, I, S * 2>::live || Tree4<CIN, I + S, S * 2>::live;
-    static __device__ __forceinline__ f32x4 eval(const f32x4 *acc) {
-        if constexpr (!Tree4<CIN, I + S, S * 2>::live) return Tree4<CIN, I, S * 2>::eval(acc);     // x + 0 == x
-        else if constexpr (!Tree4<CIN, I, S * 2>::live) return Tree4<CIN, I + S, S * 2>::eval(acc);
-        else return Tree4<CIN, I, S * 2>::eval(acc) + Tree4<CIN, I + S, S * 2>::eval(acc);
-    }
-};
-template <int CIN, int I>
-struct Tree4<CIN, I, 128> {
-    static constexpr bool live = I < 25 * CIN;
-    static __device__ __forceinline__ f32x4 eval(const f32x4 *acc) {
-        if constexpr (live) return acc[CIN == 4 ? I % 25 : I / 4];
-        else return (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-};
-
-template <int CIN> struct NAcc { static constexpr int value = CIN == 4 ? 25 : 7; };
-
-// one K step of lane class CLS: every lane gets  acc = fma(w, x, acc)  (lanes whose chain has ended carry w = 0).
-// DIAG: staged tile rows are anti-diagonals (row = kh+kw, col = kh + lane) instead of image rows (row = kh, col = kw + lane).
-template <int ABID>
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);   // D = fma(A[block ABID], B, C), A broadcast to all 16 blocks
-}
-template <int I> struct IC { static constexpr int value = I; };
-template <int N, class F, int I = 0>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) { f(IC<I>{}); static_for<N, F, I + 1>(static_cast<F &&>(f)); }
 }
 
 // PART 0 = the first chunk of 8 accumulators, PART 1 = the rest, PART 2 = everything.  The persistent kernels run part 0,
@@ -268,15 +232,24 @@ LIC360_API int lic360_cconv4_ec(void *stream, const lic360_conv_plan *p, const f
 #include "cconv4v6_dc.inc"
 #include "cconv4v3_ec.inc"
 
-LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
-                                      const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
+// mode: bit 0 = the LDS-DMA kernel of the previous generation (A/B runs), bit 1 = no two-samples-per-wave packing.
+// Internal entry (hidden visibility) so that the fused codec passes the switches it read ONCE at create time.
+int lic360_cconv4_dc_plane_mode(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod, int mode) {
     ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
-    {
-        const char *v = getenv("LIC360_DC4");                           // "3" selects the LDS-DMA kernel (A/B runs)
-        if (v && v[0] == '3' && (h <= 64 || w <= 64)) return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
-    }
-    return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
+    if ((mode & 1) && (h <= 64 || w <= 64)) return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
+    return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, (mode & 2) != 0);
+}
+// LIC360_DC4=3 / LIC360_NOPACK select the A/B variants; the environment is read once per process, not per launch
+int lic360_dc4_env_mode(void) {
+    const char *v = getenv("LIC360_DC4");
+    return ((v && v[0] == '3') ? 1 : 0) | (getenv("LIC360_NOPACK") ? 2 : 0);
+}
+LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                      const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
+    static const int mode = lic360_dc4_env_mode();
+    return lic360_cconv4_dc_plane_mode(stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, mode);
 }
 
 LIC360_API int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0) {

@@ -36,7 +36,10 @@ struct lic360_codec {
     lic360_conv_plan *plan[3];                 // first, hidden, last
     float *packed[12], *bias[12], *act[12];
     float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
-    bool use4;
+    float *packed16[12];                       // 16x16x4 MFMA weight layout of the encode-order kernel (csrc/cconv16_kernels.hip)
+    bool use4, use16;
+    int dc_mode = 0;                           // A/B switches of the decode kernel, read from the environment once, at create
+    int *e_ctr = nullptr;                      // 8 task counters of the encode kernel
     std::vector<int> h_idx, h_pidx, h_plane_start;
     int *d_idx, *d_pidx, *d_plane_start;
     float *e_x0, *e_buf[3];
@@ -334,7 +337,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     lic360_codec *c = new lic360_codec();
     memset(c->layer_set, 0, sizeof(c->layer_set));
     c->G = ngroup; c->H = h; c->W = w; c->maxB = max_batch; c->S = h + w - 1; c->P = h + w + ngroup - 2; c->HW = h * w;
-    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = nullptr;
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = c->packed16[i] = nullptr;
     int rc = 0;
     rc |= lic360_conv_plan_create(ngroup * 1, ngroup, ngroup * 4, 5, 5, &c->plan[0]);
     rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 4, 5, 6, &c->plan[1]);
@@ -366,11 +369,18 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     if (c->use4) { if (lic360_dc4_layout(h, w, &c->sk_rows, &c->sk_pitch, &c->sk_row0, &c->sk_col0)) return 1; }
     else { c->sk_rows = c->S; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
     const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = 4096;   // TAIL: band fetches may run past the last row
-    const char *force_ec = getenv("LIC360_EC4");                       // "3" keeps the row-major LDS-DMA encode kernel (A/B runs)
-    if (c->use4 && w >= 7 && !(force_ec && force_ec[0] == '3')) {
+    // encode-order kernel (environment read once, here): default = 16x16x4 MFMA on zero-haloed NCHW planes; LIC360_EC=6 the
+    // 4x4x1 kernel on wrapped diagonal-major planes, LIC360_EC4=3 (or LIC360_EC=3) the row-major LDS-DMA kernel (A/B runs)
+    const char *force_ec4 = getenv("LIC360_EC4"), *force_ec = getenv("LIC360_EC");
+    const int ec_mode = (force_ec4 && force_ec4[0] == '3') || (force_ec && force_ec[0] == '3') ? 3 : ((force_ec && force_ec[0] == '6') ? 6 : 16);
+    c->dc_mode = lic360_dc4_env_mode();
+    c->use16 = c->use4 && ec_mode == 16 && lic360_conv16_supported(c->plan[0]) && lic360_conv16_supported(c->plan[1]) && lic360_conv16_supported(c->plan[2]);
+    if (c->use16) { if (lic360_ec16_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
+    else if (c->use4 && w >= 7 && ec_mode != 3) {
         if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
     } else if (c->use4) { if (lic360_ec4_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else { c->e_hp = h; c->e_wp = w; c->e_off = 0; }
+    rc |= dmalloc(&c->e_ctr, 8);
     const size_t EPL = (size_t)c->e_hp * c->e_wp;
     rc |= dmalloc(&c->e_x0, B * G * EPL + TAIL);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], 3 * B * 4 * G * EPL + TAIL);
@@ -400,7 +410,8 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->d_plane_start);
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
-    (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab);
+    (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab); (void)hipFree(c->e_ctr);
+    for (int i = 0; i < 12; ++i) (void)hipFree(c->packed16[i]);
     for (int k = 0; k < PROF_NCLS; ++k)
         for (hipEvent_t e : c->ev[k]) (void)hipEventDestroy(e);
     delete c;
@@ -416,9 +427,11 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
         if (dmalloc(&c->bias[layer], 3 * (size_t)p->nout)) return 1;
         if (act && dmalloc(&c->act[layer], 3 * (size_t)p->nout)) return 1;
         if (c->use4 && dmalloc(&c->packed4[layer], 3 * (size_t)lic360_conv4_packed_floats(p))) return 1;
+        if (c->use16 && dmalloc(&c->packed16[layer], 3 * (size_t)lic360_conv16_packed_floats(p))) return 1;
     }
     if (lic360_conv_pack(stream, p, weight, 3, c->packed[layer])) return 1;
     if (c->use4 && lic360_conv4_pack(stream, p, weight, 3, c->packed4[layer])) return 1;
+    if (c->use16 && lic360_conv16_pack(stream, p, weight, 3, c->packed16[layer])) return 1;
     HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->layer_set[layer] = true;
@@ -444,6 +457,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
     auto ec = [&](int layer, const float *xin, const float *res, float *dst, int x_mod) -> int {
         lic360_conv_plan *p = c->plan[plan_of(layer)];
+        if (c->use16) return lic360_cconv16_ec(stream, p, xin, c->packed16[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod, c->e_ctr);
         if (c->e_wpp) return lic360_cconv4_ec_diag(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
         if (c->use4) return lic360_cconv4_ec_padded(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
         return lic360_cconv_ec_ex(stream, p, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
@@ -478,7 +492,7 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     const int *pih = c->h_pidx.data();
     auto dc = [&](int layer, const float *xin, const float *res, float *dst, int x_mod, int p) -> int {
         lic360_conv_plan *pl = c->plan[plan_of(layer)];
-        if (c->use4) return lic360_cconv4_dc_plane(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
+        if (c->use4) return lic360_cconv4_dc_plane_mode(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod, c->dc_mode);
         return lic360_cconv_dc_plane_ex(stream, pl, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3,
                                         c->d_idx, c->d_pidx, pih, p, x_mod, 1);
     };

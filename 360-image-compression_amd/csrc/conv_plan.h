@@ -18,3 +18,8 @@ struct lic360_conv_plan {
     int *d_mt_glo = nullptr, *d_mt_ghi = nullptr;
 };
 static const int LIC360_REC_PAD = 4;       // records readable past the end (software prefetch)
+
+// internal entries shared between translation units (hidden visibility; not part of include/lic360_hip.h)
+int lic360_cconv4_dc_plane_mode(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod, int mode);
+int lic360_dc4_env_mode(void);

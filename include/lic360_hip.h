@@ -154,6 +154,18 @@ int lic360_cconv4_ec(void *stream, const lic360_conv_plan *plan, const float *x,
 int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
 
+/* Encode-order variant on v_mfma_f32_16x16x4_f32 (csrc/cconv16_kernels.hip): rows = 4 consecutive groups x 4 output channels, K = 4
+ * consecutive input groups of a lane's chain; same results bit for bit as lic360_cconv_ec (extension/cconv_ec_cuda.cu:271-331).
+ * Shapes: cin in {1,4}, cout <= 4 (the latent nets).  Activations are zero-haloed NCHW planes [n][c][hp][wp], cell (r, c) at
+ * [(r+2)*wp + c+2] (lic360_ec16_layout: hp = 4*ceil(h/4)+4, wp = 16*ceil(w/16)+4); halo and round-up cells must be zero
+ * and are never written.  ctr: 8 ints of device scratch (per-XCD task counters, zeroed on the stream by the call). */
+int lic360_ec16_layout(int h, int w, int *hp, int *wp);
+int lic360_conv16_supported(const lic360_conv_plan *plan);
+long lic360_conv16_packed_floats(const lic360_conv_plan *plan);
+int lic360_conv16_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16);
+int lic360_cconv16_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
+                      const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr);
+
 /* ---- A19/A20 arithmetic coder (host side, as in the reference) ----------------------------- */
 /* Coder operates on HOST int32 tables exactly like the reference's Coder (extension/coder.h:10-63,
  * extension/coder.cpp:30-113): the op API hands it CPU tensors. */

@@ -451,3 +451,47 @@ def test_operator_extras_plain_torch(lic):
     assert float(y.grad.abs().sum()) == 0.0
     with pytest.raises(NotImplementedError):
         lo.MultiProject(171, 171)
+
+
+# ------------------------------------------------------------------ encode-order conv on 16x16x4 MFMAs, direct C-ABI call
+@pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 7, 70), (6, 4, 4, True, True, 3, 3, 5, 66), (48, 4, 4, True, True, 3, 3, 3, 64),
+                                  (48, 4, 3, True, False, 3, 6, 4, 20), (48, 1, 4, False, True, 3, 3, 4, 130), (9, 4, 4, True, True, 1, 2, 64, 9),
+                                  (7, 1, 4, False, False, 1, 1, 33, 40), (5, 4, 4, False, True, 1, 1, 9, 17), (4, 4, 3, True, False, 1, 2, 130, 8),
+                                  (48, 4, 4, True, True, 3, 24, 16, 32), (1, 4, 2, True, True, 1, 1, 5, 5), (3, 1, 1, False, False, 1, 1, 1, 1)],
+                         ids=lambda c: "g%d_%dto%d_%s_%dx%d" % (c[0], c[1], c[2], "h" if c[3] else "f", c[7], c[8]))
+def test_cconv16_ec_bit_exact(lic, case):
+    """lic360_cconv16_ec (v_mfma_f32_16x16x4_f32, K = 4 consecutive input groups) == oracle, on the zero-haloed layout; covers
+    both cin, cout < 4, group counts that are not multiples of 4, ragged tiles, many samples per XCD, first layers with cin = 4"""
+    import ctypes as C
+    G, cin, cout, hidden, act, nb, N, H, W = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    Cc, nout = G * cin, G * cout
+    w, b, a = conv_params(rng, nb if nb > 1 else None, nout, Cc, act=act)
+    if nb == 1:
+        w, b = w[None], b[None]
+        a = None if a is None else a[None]
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    x[rng.random(x.shape) < 0.2] = 0.0
+    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
+    constrain = 6 if hidden else 5
+    ref = orc.cconv_ec(x, w, b, a, G, constrain) + res
+    L = lic._lib
+    hp, wp = C.c_int(), C.c_int()
+    assert L.lic360_ec16_layout(H, W, C.byref(hp), C.byref(wp)) == 0
+    hp, wp = hp.value, wp.value
+    pad = lambda t: np.pad(t, ((0, 0), (0, 0), (2, hp - H - 2), (2, wp - W - 2)))
+    plan = C.c_void_p(0)
+    assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
+    assert L.lic360_conv16_supported(plan) == 1
+    packed = torch.empty(nb * L.lic360_conv16_packed_floats(plan), dtype=torch.float32, device="cuda:0")
+    xd, rd, wd, bd = dev(pad(x)), dev(pad(res)), dev(w), dev(b)
+    ad = dev(a) if act else None
+    out = torch.zeros((N, nout, hp, wp), dtype=torch.float32, device="cuda:0")
+    ctr = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    s = lic._stream(0)
+    P = lic._p
+    assert L.lic360_conv16_pack(s, plan, P(wd), nb, P(packed)) == 0
+    assert L.lic360_cconv16_ec(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, N, P(ctr)) == 0, L.lic360_last_error()
+    got = host(out)
+    L.lic360_conv_plan_destroy(plan)
+    assert np.array_equal(got, pad(ref)), "max abs diff %g" % np.abs(got - pad(ref)).max()
