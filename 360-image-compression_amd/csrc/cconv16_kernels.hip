@@ -24,7 +24,7 @@
 //   * a STEP = 16 input channel planes (cin = 4: four input groups; cin = 1: sixteen): their 8 x 20 halo tiles (10 KB) and
 //     the step's packed weights (4 classes x 28 slots x 64 lanes, 28 KB) go to a double-buffered LDS image by LDS-DMA
 //     (global_load_lds_dwordx4, 5 per wave and step, no staging registers: the accumulators leave none to spare)
-//     while the previous step computes; one barrier per step; per wave and step 25 weight reads + 50 operand reads
+//     two steps ahead of the MFMAs (three LDS buffers); one barrier per step; per wave and step 25 weight reads + 50 operand reads
 //     (ds_read_b32, immediate offsets only) feed 50 MFMAs of 32 cycles.
 //   * workgroups are persistent; tasks = (sample, 4 consecutive tiles, group block), group block fastest, pulled from a
 //     per-XCD counter so that the workgroups of an XCD sweep one input region together (it stays in that XCD's L2) and the
@@ -51,6 +51,7 @@
 #define C16_THREADS 512
 #define C16_COMB (C16_TH * 4 * 4 * 64)     // tile rows x classes x registers x lanes
 #define C16_TPT 4                          // tiles per task
+#define C16_NBUF 3                         // LDS step buffers: the DMAs run two steps ahead of the MFMAs
 
 static inline bool conv16_ok(const lic360_conv_plan *p) {
     return p->ksz == 5 && (p->cin == 1 || p->cin == 4) && p->cout >= 1 && p->cout <= 4 && p->ngroup >= 1 && p->ngroup <= 256;
@@ -114,7 +115,13 @@ LIC360_API int lic360_ec16_layout(int h, int w, int *hp, int *wp) {
 // LDS-DMA through inline asm (the idiom of cconv4v3_dc.inc): destination = M0 + lane * 16; the compiler does not see these
 // VMEM operations, completion is enforced by hand (C16_WAIT0 before the barrier that publishes the buffer).
 #define C16_WAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define C16_STR2(x) #x
+#define C16_STR(x) C16_STR2(x)
+#define C16_WAIT_PREV() asm volatile("s_waitcnt vmcnt(" C16_STR(C16_NDMA) ")" ::: "memory")   // all but the youngest step's DMAs
 __device__ __forceinline__ void c16_dma_x4(const float *src, unsigned lds_byte_addr) {
+#ifdef C16_EXP_NODMA
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ unsigned c16_lds_addr(const float *p) {
@@ -141,27 +148,40 @@ __host__ __device__ constexpr int c16_range_tap(int R, int i) {
     }
     return -1;
 }
-// cin = 4, one range of one step: per chain 1 weight read + 2 operand reads + 2 MFMAs, software-pipelined one chain deep (the
-// reads of chain i+1 are issued before the MFMAs of chain i); sched_barriers pin that order -- left alone, the scheduler hoists
-// every read of the range above the first MFMA and spills the accumulators.
-template <int CLS, int R>
-__device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, const float *ws) {
-    constexpr int N = c16_range_count(R);
-    float av[2], bv[2][C16_NT];
-    auto load = [&](auto tt, int into) __attribute__((always_inline)) {
-        constexpr int tap = decltype(tt)::value, kh = tap / 5, kw = tap % 5, gid = (CLS - tap) & 3;
-        av[into] = ws[tap * 64];
+// operands of one chain (cin = 4): its weight register and the operand registers of the wave's two tile rows
+struct C16Ops { float a, b[C16_NT]; };
+template <int CLS, int TAP>
+__device__ __forceinline__ void c16_load4(C16Ops &o, const float *xs, const float *ws) {
+    constexpr int kh = TAP / 5, kw = TAP % 5, gid = (CLS - TAP) & 3;
+#ifdef C16_EXP_NOLDS
+    o.a = __builtin_bit_cast(float, TAP + 0x3f800000);
+    for (int t = 0; t < C16_NT; ++t) o.b[t] = __builtin_bit_cast(float, t + kh + 0x3f000000);
+    asm volatile("" : "+v"(o.a), "+v"(o.b[0]), "+v"(o.b[1]));
+    return;
+#endif
+    o.a = ws[TAP * 64];
 #pragma unroll
-        for (int t = 0; t < C16_NT; ++t) bv[into][t] = xs[gid * C16_PLANE + (kh + t) * C16_HC + kw];
-    };
-    load(IC<c16_range_tap(R, 0)>{}, 0);
+    for (int t = 0; t < C16_NT; ++t) o.b[t] = xs[gid * C16_PLANE + (kh + t) * C16_HC + kw];
+}
+// cin = 4, one range of one step: per chain 1 weight read + 2 operand reads + 2 MFMAs, software-pipelined C16_PF chains deep
+// (the reads of chain g + C16_PF are issued before the MFMAs of chain g; the two waves of a SIMD run this code in lockstep, so
+// a partner's MFMAs do not cover a wave's LDS latency); sched_barriers pin that order -- left alone, the scheduler hoists every
+// read of the range above the first MFMA and spills the accumulators.  ops[] is a ring indexed by the chain's position g in
+// the step (ranges back to back); chains of the NEXT range are prefetched when that range runs (`more`).
+#define C16_PF 2
+__host__ __device__ constexpr int c16_range_base(int R) { return R == 0 ? 0 : (R == 1 ? 10 : 19); }
+template <int CLS, int R, class Hook>
+__device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, const float *ws, C16Ops (&ops)[C16_PF + 1], bool more, Hook &&hook) {
+    constexpr int N = c16_range_count(R), G0 = c16_range_base(R);
     static_for<N>([&](auto ii) {
-        constexpr int i = decltype(ii)::value, tap = c16_range_tap(R, i), cur = i & 1;
-        if constexpr (i + 1 < N) load(IC<c16_range_tap(R, i + 1)>{}, cur ^ 1);
+        constexpr int i = decltype(ii)::value, tap = c16_range_tap(R, i), g = G0 + i, slot = g % (C16_PF + 1), nslot = (g + C16_PF) % (C16_PF + 1);
+        if constexpr (i + C16_PF < N) c16_load4<CLS, c16_range_tap(R, i + C16_PF)>(ops[nslot], xs, ws);
+        else if constexpr (R < 2) { if (more) c16_load4<CLS, c16_range_tap(R + 1, i + C16_PF - N)>(ops[nslot], xs, ws); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < C16_NT; ++t) acc[t][tap] = mfma16(av[cur], bv[cur][t], acc[t][tap]);
+        for (int t = 0; t < C16_NT; ++t) acc[t][tap] = mfma16(ops[slot].a, ops[slot].b[t], acc[t][tap]);
         __builtin_amdgcn_sched_barrier(0);
+        hook(IC<i>{});                                                      // (range 0: the step's LDS-DMAs, spread between the chains)
     });
 }
 
@@ -175,9 +195,9 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     const int xcd = blockIdx.x & 7;
     const int ns_x = (a.N - xcd + 7) >> 3;                                  // samples of this XCD: n = xcd + 8 m
     const int n_my = ns_x * a.n_chunks * a.n_gb;
-    // ---- task queue: thread 0 pulls task numbers three tasks ahead of the compute cursor into an 8-slot LDS ring
-    // (the issue cursor reads task c + 1 while the compute cursor is still in task c - 1, and a barrier must lie between a
-    // pull and its first read)
+    // ---- task queue: thread 0 pulls task numbers four tasks ahead of the compute cursor into an 8-slot LDS ring
+    // (the issue cursor runs two steps ahead: with one-step tasks it reads task c + 3 while the compute cursor is in task c,
+    // and a barrier must lie between a pull and its first read)
     auto pull = [&](int k) __attribute__((always_inline)) { if (tid == 0) tq[k & 7] = atomicAdd(a.ctr + xcd, 1); };
     auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]); };
     // task u -> sample n, first tile, group block (group block fastest: the workgroups of an XCD share the input region)
@@ -198,6 +218,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     pull(1);
     pull(2);
     pull(3);
+    pull(4);
     __syncthreads();
     // ---- LDS-DMA windows of this wave: window j = WAVE + 8 m (m < 5) of the step image [11 x | 28 weights | 1 dump]; lane l
     // of an x window moves quad e = 64 j + l of [16 slots][41 quads] (quad 40 of a plane is padding, quads >= 656 are slack:
@@ -235,21 +256,20 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         const int T = i_tile0 + itile, ty = T / a.ntx, tx = T - ty * a.ntx;
         ixb = a.x + (long)(i_n % a.x_mod) * C * PL + (long)(ty * C16_TH) * a.wp + tx * C16_TW;
     };
-    // LDS-DMA of the issue cursor's step into buffer `buf`, then advance the cursor (an exhausted cursor keeps re-reading its
-    // last addresses: every DMA stays unconditional and inside the tensors, 5 per wave and step)
-    auto issue = [&](int buf) __attribute__((always_inline)) {
-        const int ch0 = istep * (TCS * CIN);
+    // LDS-DMA m (of 5) of the issue cursor's step into buffer `buf`; issue_advance() then moves the cursor (an exhausted cursor
+    // keeps re-reading its last addresses: every DMA stays unconditional and inside the tensors, 5 per wave and step)
+    auto issue_dma = [&](auto mm, int buf) __attribute__((always_inline)) {
+        constexpr int m = decltype(mm)::value, j = WAVE + 8 * m;
         const unsigned lb = lds_base + (unsigned)buf * (C16_BUF * 4);
         const float *wsrc = iwb + (long)istep * C16_WFL + lane * 4;
-        static_for<C16_NDMA>([&](auto mm) {
-            constexpr int m = decltype(mm)::value, j = WAVE + 8 * m;
-            if constexpr (j < C16_XWIN) {
-                int c = ch0 + xpl[m];
-                if (c > C - 1) c = C - 1;                                   // planes past the last channel only meet zero weights
-                c16_dma_x4(ixb + (long)c * PL + xg[m], lb + j * 1024);
-            } else if constexpr (j < C16_XWIN + C16_WWIN) c16_dma_x4(wsrc + (j - C16_XWIN) * 256, lb + j * 1024);
-            else c16_dma_x4(wsrc, lb + j * 1024);                           // the 40th window: dump
-        });
+        if constexpr (j < C16_XWIN) {
+            int c = istep * (TCS * CIN) + xpl[m];
+            if (c > C - 1) c = C - 1;                                       // planes past the last channel only meet zero weights
+            c16_dma_x4(ixb + (long)c * PL + xg[m], lb + j * 1024);
+        } else if constexpr (j < C16_XWIN + C16_WWIN) c16_dma_x4(wsrc + (j - C16_XWIN) * 256, lb + j * 1024);
+        else c16_dma_x4(wsrc, lb + j * 1024);                               // the 40th window: dump
+    };
+    auto issue_advance = [&]() __attribute__((always_inline)) {
         if (ivalid) {
             if (++istep == i_nsteps) {
                 istep = 0;
@@ -264,10 +284,15 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
             }
         }
     };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        static_for<C16_NDMA>([&](auto mm) { issue_dma(mm, buf); });
+        issue_advance();
+    };
     issue_task();
     if (!ivalid) return;                                                    // uniform: the whole workgroup has no task
     issue_tile();
     issue(0);
+    issue(1);
     // ---- compute cursor
     int cq = 0, ctile = 0, cstep = 0, c_nsteps, c_tile0, c_n, c_gb;
     decode(task(0), c_n, c_tile0, c_gb);
@@ -281,21 +306,31 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     // operand addresses: lane (k = l >> 4, j = l & 15) reads plane slot 4 k + {gid | sq}, row 2 PS + t + kh, column j + kw
     const int xlane = (lane >> 4) * 4 * C16_PLANE + (C16_NT * PS) * C16_HC + (lane & 15);
     const int wlane = C16_XFL + CLS * C16_SLOTS * 64 + lane;
-    C16_WAIT0();
+    C16_WAIT_PREV();
     __syncthreads();
     // (comb is double-buffered by tile parity: with one-step tiles the next tile's partial sums are written before the
     // barrier that would separate them from this tile's reads)
-    int s = 0, ntile = 0;
+    int cur = 0, ntile = 0;                                                 // cur: LDS buffer of the step being computed
     bool done = false;
     do {
-        const float *xs = lds + (s & 1) * C16_BUF + xlane, *ws = lds + (s & 1) * C16_BUF + wlane;
-        issue((s + 1) & 1);                                                 // next step's DMAs fly while this step computes
+        const float *xs = lds + cur * C16_BUF + xlane, *ws = lds + cur * C16_BUF + wlane;
+        const int nbuf = cur >= 1 ? cur - 1 : C16_NBUF - 1;                  // DMAs of the step after next go to (cur + 2) mod 3
+        if constexpr (CIN == 1) issue(nbuf);
         const int g0 = c_gb * 4, dl = g0 + 7 + a.hidden - cstep * TCS;      // tap diagonals d >= dl carry only zero weights
         if constexpr (CIN == 4) {
             // chains in three ranges of tap diagonals (d <= 3, 4..5, 6..8): the later ranges die first as tc grows
-            c16_range4<CLS, 0>(acc, xs, ws);
-            if (dl > 4) c16_range4<CLS, 1>(acc, xs, ws);
-            if (dl > 6) c16_range4<CLS, 2>(acc, xs, ws);
+            C16Ops ops[C16_PF + 1];
+            static_for<C16_PF>([&](auto ii) { c16_load4<CLS, c16_range_tap(0, decltype(ii)::value)>(ops[decltype(ii)::value], xs, ws); });
+            // the step's 5 DMAs are issued between the chains of range 0 (one after every second chain): issued together at the
+            // top of the step they keep both waves of a SIMD off the matrix pipe for their whole issue time
+            c16_range4<CLS, 0>(acc, xs, ws, ops, dl > 4, [&](auto ii) __attribute__((always_inline)) {
+                constexpr int i = decltype(ii)::value;
+                if constexpr ((i & 1) == 0 && i / 2 < C16_NDMA) issue_dma(IC<i / 2>{}, nbuf);
+            });
+            issue_advance();
+            auto nohook = [](auto) __attribute__((always_inline)) {};
+            if (dl > 4) c16_range4<CLS, 1>(acc, xs, ws, ops, dl > 6, nohook);
+            if (dl > 6) c16_range4<CLS, 2>(acc, xs, ws, ops, false, nohook);
         } else {
             static_for<4>([&](auto ss) {
                 constexpr int sq = decltype(ss)::value;
@@ -328,7 +363,10 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
             }
         }
-        C16_WAIT0();                                                        // own DMAs of the next step have landed
+        C16_WAIT_PREV();                                                    // own DMAs of the NEXT step (issued a step ago) have landed
+#ifdef C16_EXP_NOBAR
+        if (last)
+#endif
         __syncthreads();
         if (last) {
             // wave w finishes tile row w >> 1, output channels 2 (w & 1), 2 (w & 1) + 1 of the four groups: (F0 + F2) + (F1 + F3)
@@ -357,20 +395,20 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
             if (ctile == C16_TPT || c_tile0 + ctile >= a.ntiles) {
                 ctile = 0;
                 ++cq;
-                pull(cq + 3);                                               // first read two iterations (barriers) later
+                pull(cq + 4);                                               // first read at least one barrier later
                 const int u = task(cq);
                 if (u < n_my) { decode(u, c_n, c_tile0, c_gb); c_nsteps = steps_of(c_gb); }
                 else done = true;
             }
         } else ++cstep;
-        ++s;
+        cur = cur + 1 == C16_NBUF ? 0 : cur + 1;
     } while (!done);
     C16_WAIT0();                                                            // no DMA may outlive the workgroup's LDS
 }
 
 template <int CIN>
 __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
-    __shared__ float lds[2 * C16_BUF];
+    __shared__ float lds[C16_NBUF * C16_BUF];
     __shared__ float comb[2 * C16_COMB];
     __shared__ int tq[8];
     const int tid = threadIdx.x, lane = tid & 63;

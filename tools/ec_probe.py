@@ -1,16 +1,18 @@
-import os, sys, time
-sys.path.insert(0, "360-image-compression_amd"); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+"""one encode of PB images (default 32) through the fused codec: the subject of the rocprofv3 runs behind profiles/*ec*"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("360-image-compression_amd", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
 import torch, numpy as np
-import ref_codec as rc
+from util import latent, make_main_params
 from lic360_fused import FusedCodec
-G,H,W,B = 48,64,128,8
-layers = rc.make_main_params(1003, G)
-fc = FusedCodec(G,H,W,max_batch=B); fc.load_layers(layers)
-from util import latent
-items=[latent(np.random.default_rng(i),G,H,W) for i in range(B)]
-code=torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask=torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
-fc.encode_async(code,mask); torch.cuda.synchronize()
+G, H, W, B = 48, 64, 128, int(os.environ.get("PB", 32))
+layers = make_main_params(1003, G)
+fc = FusedCodec(G, H, W, max_batch=B); fc.load_layers(layers)
+items = [latent(np.random.default_rng(i), G, H, W) for i in range(B)]
+code = torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask = torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
+fc.encode_async(code, mask); torch.cuda.synchronize()
 fc.profile(True)
-fc.encode_async(code,mask); torch.cuda.synchronize()
-p=fc.profile_read()
-print("ec hidden ms per launch (B=8): %.3f" % (p["ec_ms"]/p["ec_launches"]))
+fc.encode_async(code, mask); torch.cuda.synchronize()
+for k, (ms, n) in fc.profile_read().items():
+    if n: print("%-12s %4d launches  %.4f ms each" % (k, n, ms / n))
