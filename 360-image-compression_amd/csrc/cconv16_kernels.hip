@@ -34,6 +34,7 @@
 #include "common.h"
 #include "conv_plan.h"
 #include "cconv_tree.h"
+#include "gmm_tables.h"
 
 #define C16_SLOTS 28                       // weight slots per lane class and step (cin = 4: 25 taps; cin = 1: 4 sub-quads x 7 taps)
 #define C16_TH 4                           // tile rows
@@ -134,6 +135,11 @@ struct C16Args {
     int *ctr;                                  // 8 task counters (one per XCD), zeroed by the host before the launch
     int G, cout, hidden, H, W, hp, wp, npb, x_mod, N;
     int n_gb, ntx, ntiles, n_chunks, NS;
+    // FUSE (last layer of the latent net + CDF-table build, SURVEY.md §7 k_cconv_ec_last_gmm): N = images, the three stacked
+    // nets [weight, sigma, mu] of an image are swept one after the other inside a task
+    const float *code, *mask;                  // [N, G, H, W] symbols / importance mask
+    const int *pidx, *plane_start;             // scan-order prefix tables (code_contex_cuda.cu:19-31) / first record of a plane
+    uint2 *rec;                                // [N][G*H*W] (cdf[sym], cdf[sym+1]) in coding order
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -170,8 +176,9 @@ __device__ __forceinline__ void c16_load4(C16Ops &o, const float *xs, const floa
 // the step (ranges back to back); chains of the NEXT range are prefetched when that range runs (`more`).
 #define C16_PF 2
 __host__ __device__ constexpr int c16_range_base(int R) { return R == 0 ? 0 : (R == 1 ? 10 : 19); }
-template <int CLS, int R, class Hook>
+template <int CLS, int R, bool FIRST, class Hook>
 __device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, const float *ws, C16Ops (&ops)[C16_PF + 1], bool more, Hook &&hook) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};                                 // FIRST: the first step of a tile starts every chain from C = 0
     constexpr int N = c16_range_count(R), G0 = c16_range_base(R);
     static_for<N>([&](auto ii) {
         constexpr int i = decltype(ii)::value, tap = c16_range_tap(R, i), g = G0 + i, slot = g % (C16_PF + 1), nslot = (g + C16_PF) % (C16_PF + 1);
@@ -179,14 +186,16 @@ __device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, co
         else if constexpr (R < 2) { if (more) c16_load4<CLS, c16_range_tap(R + 1, i + C16_PF - N)>(ops[nslot], xs, ws); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < C16_NT; ++t) acc[t][tap] = mfma16(ops[slot].a, ops[slot].b[t], acc[t][tap]);
+        for (int t = 0; t < C16_NT; ++t) acc[t][tap] = mfma16(ops[slot].a, ops[slot].b[t], FIRST ? zero4 : acc[t][tap]);
         __builtin_amdgcn_sched_barrier(0);
         hook(IC<i>{});                                                      // (range 0: the step's LDS-DMAs, spread between the chains)
     });
 }
 
-template <int CIN, int CLS, int PS>
+template <int CIN, int CLS, int PS, bool FUSE>
 __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *comb, int *tq, const int tid, const int lane) {
+    static_assert(!FUSE || CIN == 4, "the fused table build belongs to the last (cin = 4) layer");
+    constexpr int NSUB = FUSE ? 3 : 1;                                      // FUSE: the 3 stacked nets of an image, one after the other per tile
     constexpr int NA = NAcc<CIN>::value;
     constexpr int TCS = CIN == 4 ? 4 : 16;                                  // input groups per step
     constexpr int WAVE = PS * 4 + CLS;
@@ -240,7 +249,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     }
     const unsigned lds_base = c16_lds_addr(lds);
     // ---- issue cursor
-    int iq = 0, itile = 0, istep = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;
+    int iq = 0, itile = 0, istep = 0, inet = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;
     bool ivalid = false;
     const float *ixb = a.x, *iwb = a.packed;                                // x of (sample, tile), weights of (net, group block)
     auto issue_task = [&]() __attribute__((always_inline)) {
@@ -249,12 +258,14 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         if (ivalid) {
             decode(u, i_n, i_tile0, i_gb);
             i_nsteps = steps_of(i_gb);
-            iwb = a.packed + ((long)(i_n / a.npb) * a.n_gb + i_gb) * a.NS * C16_WFL;
+            if constexpr (!FUSE) iwb = a.packed + ((long)(i_n / a.npb) * a.n_gb + i_gb) * a.NS * C16_WFL;
         }
     };
     auto issue_tile = [&]() __attribute__((always_inline)) {
         const int T = i_tile0 + itile, ty = T / a.ntx, tx = T - ty * a.ntx;
-        ixb = a.x + (long)(i_n % a.x_mod) * C * PL + (long)(ty * C16_TH) * a.wp + tx * C16_TW;
+        const int sample = FUSE ? inet * a.N + i_n : i_n;                   // FUSE: sample of net `inet` = inet * images + image
+        ixb = a.x + (long)(sample % a.x_mod) * C * PL + (long)(ty * C16_TH) * a.wp + tx * C16_TW;
+        if constexpr (FUSE) iwb = a.packed + ((long)inet * a.n_gb + i_gb) * a.NS * C16_WFL;
     };
     // LDS-DMA m (of 5) of the issue cursor's step into buffer `buf`; issue_advance() then moves the cursor (an exhausted cursor
     // keeps re-reading its last addresses: every DMA stays unconditional and inside the tensors, 5 per wave and step)
@@ -273,14 +284,17 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         if (ivalid) {
             if (++istep == i_nsteps) {
                 istep = 0;
-                ++itile;
-                if (itile == C16_TPT || i_tile0 + itile >= a.ntiles) {
-                    itile = 0;
-                    ++iq;
-                    issue_task();
+                if (++inet == NSUB) {
+                    inet = 0;
+                    ++itile;
+                    if (itile == C16_TPT || i_tile0 + itile >= a.ntiles) {
+                        itile = 0;
+                        ++iq;
+                        issue_task();
+                    }
                 }
                 if (ivalid) issue_tile();
-                else { istep = i_nsteps - 1; }                               // idle: stay on the last step
+                else { istep = i_nsteps - 1; inet = NSUB - 1; }               // idle: stay on the last step
             }
         }
     };
@@ -294,20 +308,60 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     issue(0);
     issue(1);
     // ---- compute cursor
-    int cq = 0, ctile = 0, cstep = 0, c_nsteps, c_tile0, c_n, c_gb;
+    int cq = 0, ctile = 0, cstep = 0, cnet = 0, c_nsteps, c_tile0, c_n, c_gb;
     decode(task(0), c_n, c_tile0, c_gb);
     c_nsteps = steps_of(c_gb);
     f32x4 acc[C16_NT][NA];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CIN == 1) {                                               // cin = 4 starts its chains with C = 0 in the first step
 #pragma unroll
-    for (int t = 0; t < C16_NT; ++t)
+        for (int t = 0; t < C16_NT; ++t)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
+            for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
+    }
     // operand addresses: lane (k = l >> 4, j = l & 15) reads plane slot 4 k + {gid | sq}, row 2 PS + t + kh, column j + kw
     const int xlane = (lane >> 4) * 4 * C16_PLANE + (C16_NT * PS) * C16_HC + (lane & 15);
     const int wlane = C16_XFL + CLS * C16_SLOTS * 64 + lane;
     C16_WAIT_PREV();
     __syncthreads();
+    float e_bias[2] = {0.f, 0.f}, e_act[2] = {0.f, 0.f}, e_res[2] = {0.f, 0.f};
+    long e_oi[2] = {0, 0};
+    bool e_ok = false;
+    const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
+    // FUSE: table build of a finished tile.  It runs at the top of the NEXT tile's first step -- where every accumulator is dead
+    // (the first step starts all chains from C = 0), so its ~90 registers do not compete with them -- or after the loop.
+    bool tb_pending = false;
+    int tb_T = 0, tb_n = 0, tb_gb = 0;
+    auto tables = [&]() __attribute__((always_inline)) {
+        // all three nets of the tile are in LDS: one thread per symbol (4 groups x 64 positions) builds the 9-entry CDF
+        // (softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159) and writes the symbol's
+        // (cdf[sym], cdf[sym+1]) record at its place in coding order (tile_extract_cuda.cu:36-41)
+        __syncthreads();
+        if (tid < 256) {
+            const int ty = tb_T / a.ntx, tx = tb_T - ty * a.ntx;
+            const int q = tid >> 6, pos = tid & 63, th = ty * C16_TH + (pos >> 4), tw = tx * C16_TW + (pos & 15), g = tb_gb * 4 + q;
+            if (g < G && th < a.H && tw < a.W) {
+                const long HW = (long)a.H * a.W, i = (((long)tb_n * G + g) * a.H + th) * a.W + tw;
+                const int sd = th + tw, p = sd + g, la = p >= G ? p - G + 1 : 0;
+                const long k = a.plane_start[p] + (a.pidx[sd] - a.pidx[la]) + (th - (sd >= a.W ? sd - a.W + 1 : 0));
+                uint2 rv = make_uint2(0u, 0u);
+                if (!(a.mask[i] < 0.5f)) {                                   // coder.cpp:79
+                    float v[9];
+#pragma unroll
+                    for (int net = 0; net < 3; ++net)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + ((net * 4 + q) * 3 + c) * 64 + pos];
+                    int Tb[9];
+                    gmm_cdf9(v, v + 3, v + 6, Tb);
+                    int sym = (int)a.code[i];
+                    sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
+                    rv = make_uint2((unsigned)Tb[sym], (unsigned)Tb[sym + 1]);
+                }
+                a.rec[(long)tb_n * G * HW + k] = rv;
+            }
+        }
+        tb_pending = false;
+    };
     // (comb is double-buffered by tile parity: with one-step tiles the next tile's partial sums are written before the
     // barrier that would separate them from this tile's reads)
     int cur = 0, ntile = 0;                                                 // cur: LDS buffer of the step being computed
@@ -317,20 +371,56 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         const int nbuf = cur >= 1 ? cur - 1 : C16_NBUF - 1;                  // DMAs of the step after next go to (cur + 2) mod 3
         if constexpr (CIN == 1) issue(nbuf);
         const int g0 = c_gb * 4, dl = g0 + 7 + a.hidden - cstep * TCS;      // tap diagonals d >= dl carry only zero weights
+        // bias / PReLU slope / residual of the tile are fetched at the START of its last step, from clamped addresses (they
+        // are the oldest loads in flight when the epilogue needs them: waiting for them there stalled all eight waves for
+        // three dependent memory round trips per tile, ~25 % of the kernel)
+        const bool last = cstep + 1 == c_nsteps;
+        if (last) {
+            const int T = c_tile0 + ctile, ty = T / a.ntx, tx = T - ty * a.ntx;
+            const int q = lane >> 4, j = lane & 15;
+            const int y = ty * C16_TH + (WAVE >> 1), x = tx * C16_TW + j, g = c_gb * 4 + q;
+            e_ok = g < G && y < a.H && x < a.W;
+            const int gc = g < G ? g : G - 1;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * (WAVE & 1) + rr, rc = r < a.cout ? r : a.cout - 1;
+                const int o = gc * a.cout + rc, bid = (FUSE ? cnet : c_n / a.npb) * nout + o;
+                e_oi[rr] = ((long)c_n * nout + o) * PL + (long)((y < a.H ? y : a.H - 1) + 2) * a.wp + (x < a.W ? x : a.W - 1) + 2;
+                e_bias[rr] = a.bias[bid];
+                e_act[rr] = act_p[bid];
+                e_res[rr] = res_p[a.residual ? e_oi[rr] : 0];
+            }
+        }
         if constexpr (CIN == 4) {
             // chains in three ranges of tap diagonals (d <= 3, 4..5, 6..8): the later ranges die first as tc grows
             C16Ops ops[C16_PF + 1];
             static_for<C16_PF>([&](auto ii) { c16_load4<CLS, c16_range_tap(0, decltype(ii)::value)>(ops[decltype(ii)::value], xs, ws); });
             // the step's 5 DMAs are issued between the chains of range 0 (one after every second chain): issued together at the
             // top of the step they keep both waves of a SIMD off the matrix pipe for their whole issue time
-            c16_range4<CLS, 0>(acc, xs, ws, ops, dl > 4, [&](auto ii) __attribute__((always_inline)) {
+            auto dmahook = [&](auto ii) __attribute__((always_inline)) {
                 constexpr int i = decltype(ii)::value;
                 if constexpr ((i & 1) == 0 && i / 2 < C16_NDMA) issue_dma(IC<i / 2>{}, nbuf);
-            });
-            issue_advance();
+            };
             auto nohook = [](auto) __attribute__((always_inline)) {};
-            if (dl > 4) c16_range4<CLS, 1>(acc, xs, ws, ops, dl > 6, nohook);
-            if (dl > 6) c16_range4<CLS, 2>(acc, xs, ws, ops, false, nohook);
+            if (cstep == 0) {                                               // every chain starts here (dead ones on zero weights): no zeroing pass
+                if constexpr (FUSE) { if (tb_pending) tables(); }
+                c16_range4<CLS, 0, true>(acc, xs, ws, ops, true, dmahook);
+                issue_advance();
+                c16_range4<CLS, 1, true>(acc, xs, ws, ops, true, nohook);
+                c16_range4<CLS, 2, true>(acc, xs, ws, ops, false, nohook);
+            } else {
+#ifdef C16_EXP_REPEAT
+                for (int rep = 0; rep < C16_EXP_REPEAT - 1; ++rep) {
+                    c16_range4<CLS, 0, false>(acc, xs, ws, ops, true, nohook);
+                    c16_range4<CLS, 1, false>(acc, xs, ws, ops, true, nohook);
+                    c16_range4<CLS, 2, false>(acc, xs, ws, ops, true, nohook);
+                }
+#endif
+                c16_range4<CLS, 0, false>(acc, xs, ws, ops, dl > 4, dmahook);
+                issue_advance();
+                if (dl > 4) c16_range4<CLS, 1, false>(acc, xs, ws, ops, dl > 6, nohook);
+                if (dl > 6) c16_range4<CLS, 2, false>(acc, xs, ws, ops, false, nohook);
+            }
         } else {
             static_for<4>([&](auto ss) {
                 constexpr int sq = decltype(ss)::value;
@@ -352,15 +442,20 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 });
             });
         }
-        const bool last = cstep + 1 == c_nsteps;
+#ifdef C16_EXP_NOEPI
+        if (last && c_n < 0) {
+#else
         if (last) {
+#endif
 #pragma unroll
             for (int t = 0; t < C16_NT; ++t) {
                 const f32x4 part = Tree4<CIN, CLS, 4>::eval(acc[t]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) comb[(ntile & 1) * C16_COMB + (((PS * C16_NT + t) * 4 + CLS) * 4 + r) * 64 + lane] = part[r];
+                for (int r = 0; r < 4; ++r) comb[(FUSE ? 0 : (ntile & 1)) * C16_COMB + (((PS * C16_NT + t) * 4 + CLS) * 4 + r) * 64 + lane] = part[r];
+                if constexpr (CIN == 1) {
 #pragma unroll
-                for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
+                    for (int i = 0; i < NA; ++i) acc[t][i] = zero4;
+                }
             }
         }
         C16_WAIT_PREV();                                                    // own DMAs of the NEXT step (issued a step ago) have landed
@@ -370,27 +465,33 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         __syncthreads();
         if (last) {
             // wave w finishes tile row w >> 1, output channels 2 (w & 1), 2 (w & 1) + 1 of the four groups: (F0 + F2) + (F1 + F3)
-            const int T = c_tile0 + ctile, ty = T / a.ntx, tx = T - ty * a.ntx;
             constexpr int trow = WAVE >> 1;
-            const int q = lane >> 4, j = lane & 15;
-            const int y = ty * C16_TH + trow, x = tx * C16_TW + j, g = c_gb * 4 + q;
+#ifdef C16_EXP_NOEPI
+            if (c_n < 0)
+#endif
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 constexpr int rbase = 2 * (WAVE & 1);
                 const int r = rbase + rr;
-                const float *cb = comb + (ntile & 1) * C16_COMB + ((trow * 4) * 4 + r) * 64 + lane;
+                const float *cb = comb + (FUSE ? 0 : (ntile & 1)) * C16_COMB + ((trow * 4) * 4 + r) * 64 + lane;
                 const float f0 = cb[0], f1 = cb[4 * 64], f2 = cb[8 * 64], f3 = cb[12 * 64];
-                if (g < G && r < a.cout && y < a.H && x < a.W) {
-                    const int o = g * a.cout + r, bid = (c_n / a.npb) * nout + o;
-                    float sv = ((f0 + f2) + (f1 + f3)) + a.bias[bid];
-                    if (a.act) sv = sv > 0 ? sv : sv * a.act[bid];            // cconv_ec_cuda.cu:311-312
-                    const long oi = ((long)c_n * nout + o) * PL + (long)(y + 2) * a.wp + x + 2;
-                    if (a.residual) sv = sv + a.residual[oi];
-                    a.out[oi] = sv;
-                }
+                float sv = ((f0 + f2) + (f1 + f3)) + e_bias[rr];
+                if (a.act) sv = sv > 0 ? sv : sv * e_act[rr];                // cconv_ec_cuda.cu:311-312
+                if (a.residual) sv = sv + e_res[rr];
+                if constexpr (FUSE) {                                       // y of (net, group q, channel r) at tile position (trow, j)
+                    if (r < 3) comb[C16_COMB + ((cnet * 4 + (lane >> 4)) * 3 + r) * 64 + trow * 16 + (lane & 15)] = sv;
+                } else if (e_ok && r < a.cout) a.out[e_oi[rr]] = sv;
+            }
+            if constexpr (FUSE) {
+                if (cnet == NSUB - 1) { tb_pending = true; tb_T = c_tile0 + ctile; tb_n = c_n; tb_gb = c_gb; }
             }
             cstep = 0;
             ++ntile;
+            if constexpr (FUSE) {
+                if (c_nsteps == 1) __syncthreads();                         // one-step tiles: the single comb buffer is rewritten before the next barrier
+            }
+            if (++cnet < NSUB) { cur = cur + 1 == C16_NBUF ? 0 : cur + 1; continue; }   // FUSE: same tile, next net
+            cnet = 0;
             ++ctile;
             if (ctile == C16_TPT || c_tile0 + ctile >= a.ntiles) {
                 ctile = 0;
@@ -403,26 +504,39 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         } else ++cstep;
         cur = cur + 1 == C16_NBUF ? 0 : cur + 1;
     } while (!done);
+    if constexpr (FUSE) { if (tb_pending) tables(); }
     C16_WAIT0();                                                            // no DMA may outlive the workgroup's LDS
 }
 
-template <int CIN>
+template <int CIN, bool FUSE>
 __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
     __shared__ float lds[C16_NBUF * C16_BUF];
-    __shared__ float comb[2 * C16_COMB];
+    __shared__ float comb[2 * C16_COMB];                                   // FUSE: [partial sums | y of the tile's three nets]
     __shared__ int tq[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     switch (wave) {
-        case 0: c16_body<CIN, 0, 0>(a, lds, comb, tq, tid, lane); break;
-        case 1: c16_body<CIN, 1, 0>(a, lds, comb, tq, tid, lane); break;
-        case 2: c16_body<CIN, 2, 0>(a, lds, comb, tq, tid, lane); break;
-        case 3: c16_body<CIN, 3, 0>(a, lds, comb, tq, tid, lane); break;
-        case 4: c16_body<CIN, 0, 1>(a, lds, comb, tq, tid, lane); break;
-        case 5: c16_body<CIN, 1, 1>(a, lds, comb, tq, tid, lane); break;
-        case 6: c16_body<CIN, 2, 1>(a, lds, comb, tq, tid, lane); break;
-        default: c16_body<CIN, 3, 1>(a, lds, comb, tq, tid, lane); break;
+        case 0: c16_body<CIN, 0, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
+        case 1: c16_body<CIN, 1, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
+        case 2: c16_body<CIN, 2, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
+        case 3: c16_body<CIN, 3, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
+        case 4: c16_body<CIN, 0, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
+        case 5: c16_body<CIN, 1, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
+        case 6: c16_body<CIN, 2, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
+        default: c16_body<CIN, 3, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
     }
+}
+
+static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w) {
+    a.G = p->ngroup; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w;
+    if (lic360_ec16_layout(h, w, &a.hp, &a.wp)) return 2;
+    a.n_gb = conv16_ngb(p);
+    a.ntx = (w + C16_TW - 1) / C16_TW;
+    a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
+    a.n_chunks = (a.ntiles + C16_TPT - 1) / C16_TPT;
+    a.NS = conv16_nsteps_max(p);
+    a.code = a.mask = nullptr; a.pidx = a.plane_start = nullptr; a.rec = nullptr;
+    return 0;
 }
 
 // x / residual / out: [n][C | nout][hp][wp] zero-haloed planes (lic360_ec16_layout).  ctr: 8 ints of device scratch.
@@ -431,17 +545,35 @@ LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const 
     ARG_CHECK(p && conv16_ok(p) && x && packed16 && bias && out && ctr && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
     C16Args a;
     a.x = x; a.packed = packed16; a.bias = bias; a.act = act; a.residual = residual; a.out = out; a.ctr = ctr;
-    a.G = p->ngroup; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w; a.npb = n / nb; a.x_mod = x_mod; a.N = n;
-    if (lic360_ec16_layout(h, w, &a.hp, &a.wp)) return 2;
-    a.n_gb = conv16_ngb(p);
-    a.ntx = (w + C16_TW - 1) / C16_TW;
-    a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
-    a.n_chunks = (a.ntiles + C16_TPT - 1) / C16_TPT;
-    a.NS = conv16_nsteps_max(p);
+    a.npb = n / nb; a.x_mod = x_mod; a.N = n;
+    if (c16_fill_args(a, p, h, w)) return 2;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));
-    if (p->cin == 4) hipLaunchKernelGGL(k_cconv16<4>, dim3(256), dim3(C16_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_cconv16<1>, dim3(256), dim3(C16_THREADS), 0, s, a);
+    if (p->cin == 4) hipLaunchKernelGGL((k_cconv16<4, false>), dim3(256), dim3(C16_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_cconv16<1, false>), dim3(256), dim3(C16_THREADS), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Last layer of the latent entropy model fused with the CDF-table build (SURVEY.md §7 `k_cconv_ec_last_gmm`; replaces the last
+// CconvEcBatch + TileExtractBatch + EntropyBatchGmmTable of EntEncoderFast.forward, test/lic360_demo.py:132-140,
+// extension/entropy_gmm_table_cuda.cu:138-191): x = [3 * images][C][hp][wp] activations of the three stacked nets
+// [weight, sigma, mu] (net-major), cout must be 3; the nets' outputs of a tile meet in LDS and never reach HBM; per symbol
+// only (cdf[sym], cdf[sym+1]) is written, at the symbol's place in coding order.  pidx / plane_start: device copies of the
+// CodeContex prefix table and of the first-record-of-plane table.
+LIC360_API int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                                        const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
+                                        void *rec, int images, int h, int w, int *ctr) {
+    ARG_CHECK(p && conv16_ok(p) && p->cin == 4 && p->cout == 3 && x && packed16 && bias && code && mask && pidx_dev && plane_start_dev && rec &&
+              ctr && images > 0 && h > 0 && w > 0);
+    C16Args a;
+    a.x = x; a.packed = packed16; a.bias = bias; a.act = nullptr; a.residual = nullptr; a.out = nullptr; a.ctr = ctr;
+    a.npb = images; a.x_mod = 3 * images; a.N = images;
+    if (c16_fill_args(a, p, h, w)) return 2;
+    a.code = code; a.mask = mask; a.pidx = pidx_dev; a.plane_start = plane_start_dev; a.rec = (uint2 *)rec;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));
+    hipLaunchKernelGGL((k_cconv16<4, true>), dim3(256), dim3(C16_THREADS), 0, s, a);
     LAUNCH_CHECK();
     return 0;
 }

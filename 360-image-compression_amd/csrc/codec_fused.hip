@@ -13,6 +13,7 @@
 #include "conv_plan.h"
 #include "ac_core.h"
 #include "lic360_exact_math.h"
+#include "gmm_tables.h"
 #include <vector>
 #include <cstring>
 #include <algorithm>
@@ -37,7 +38,7 @@ struct lic360_codec {
     float *packed[12], *bias[12], *act[12];
     float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
     float *packed16[12];                       // 16x16x4 MFMA weight layout of the encode-order kernel (csrc/cconv16_kernels.hip)
-    bool use4, use16;
+    bool use4, use16, fuse_tables = true;      // fuse_tables: LIC360_EC_FUSE=0 keeps the separate table kernel (A/B runs)
     int dc_mode = 0;                           // A/B switches of the decode kernel, read from the environment once, at create
     int *e_ctr = nullptr;                      // 8 task counters of the encode kernel
     std::vector<int> h_idx, h_pidx, h_plane_start;
@@ -96,22 +97,6 @@ __global__ void k_enc_prep(const float *__restrict__ code, const float *__restri
         x0[pl * hp * wp + o] = v;
         if (dup >= 0) x0[pl * hp * wp + dup] = v;
     }
-}
-
-// 9-entry GMM CDF of one symbol from the three nets' outputs (weights, sigma, mu; 3 components each)
-__device__ __forceinline__ void gmm_cdf9(const float *lw_in, const float *ld_in, const float *lm, int *T) {
-    float lw[3] = {lw_in[0], lw_in[1], lw_in[2]}, ld[3];
-    lic360_softmax_inplace(lw, 3);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ld[i] = lic360_sigma_floor(ld_in[i], 1e-6f);
-    float t[9];
-    t[0] = 0.0f;
-    t[8] = 65536.0f;
-#pragma unroll
-    for (int pt = 1; pt < 8; ++pt) t[pt] = (float)lic360_gmm_cdf_entry(pt, 3.5f, 65536.0f, lw, ld, lm, 3);
-    lic360_cdf_fixup(t, 8, 0);
-#pragma unroll
-    for (int pt = 0; pt < 9; ++pt) T[pt] = (int)t[pt];
 }
 
 // one thread per latent element (NCHW-linear, coalesced reads); the (cdf[sym], cdf[sym+1]) pair is
@@ -381,6 +366,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     } else if (c->use4) { if (lic360_ec4_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else { c->e_hp = h; c->e_wp = w; c->e_off = 0; }
     rc |= dmalloc(&c->e_ctr, 8);
+    { const char *f = getenv("LIC360_EC_FUSE"); c->fuse_tables = !(f && f[0] == '0'); }
     const size_t EPL = (size_t)c->e_hp * c->e_wp;
     rc |= dmalloc(&c->e_x0, B * G * EPL + TAIL);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], 3 * B * 4 * G * EPL + TAIL);
@@ -471,6 +457,15 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (rc) return 1;
+    if (c->use16 && c->fuse_tables) {
+        // last layer + CDF tables in one kernel: the nets' outputs never reach HBM (no y buffer, no k_enc_tables)
+        PROF(c, PROF_EC_LAST, s, rc |= lic360_cconv16_ec_tables(stream, c->plan[2], cur, c->packed16[11], c->bias[11], code, mask, c->d_pidx,
+                                                                c->d_plane_start, c->e_rec, B, H, W, c->e_ctr));
+        if (rc) return 1;
+        PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
+        LAUNCH_CHECK();
+        return 0;
+    }
     PROF(c, PROF_EC_LAST, s, rc |= ec(11, cur, nullptr, t1, 3 * B));
     if (rc) return 1;
     PROF(c, PROF_ENC_TABLES, s, hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx,

@@ -166,6 +166,16 @@ int lic360_conv16_pack(void *stream, const lic360_conv_plan *plan, const float *
 int lic360_cconv16_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr);
 
+/* Last layer of the latent entropy model with the CDF-table build fused into its epilogue (SURVEY.md §7 k_cconv_ec_last_gmm;
+ * replaces the last CconvEcBatch.forward + TileExtractBatch + EntropyBatchGmmTable.forward_batch of
+ * test/lic360_demo.py:132-140, extension/entropy_gmm_table_cuda.cu:138-191): x = activations of the three stacked nets
+ * [weight, sigma, mu], [3*images][C][hp][wp] net-major in the lic360_ec16_layout; code / mask [images, G, h, w]; pidx_dev /
+ * plane_start_dev = device copies of CodeContex's prefix table [h+w] and of the index of each plane's first record
+ * [h+w+G-1]; rec = uint32 pairs [images][G*h*w] (cdf[sym], cdf[sym+1]) in coding order, (0,0) where masked. */
+int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
+                             const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
+                             void *rec, int images, int h, int w, int *ctr);
+
 /* ---- A19/A20 arithmetic coder (host side, as in the reference) ----------------------------- */
 /* Coder operates on HOST int32 tables exactly like the reference's Coder (extension/coder.h:10-63,
  * extension/coder.cpp:30-113): the op API hands it CPU tensors. */

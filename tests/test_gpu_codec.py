@@ -109,7 +109,8 @@ def test_fused_codec_matches_oracle(G, H, W, B, seed):
 @pytest.mark.parametrize("G,H,W,B,seed", [(6, 8, 12, 2, 21), (4, 66, 10, 1, 22)])
 def test_fused_codec_previous_generation_kernels(monkeypatch, G, H, W, B, seed):
     """The LDS-DMA / row-major conv kernels kept as A/B references (LIC360_DC4=3, LIC360_EC4=3), the 4x4x1 encode kernel on the
-    wrapped-diagonal layout (LIC360_EC=6; the default encode kernel is the 16x16x4 one) and the generic 16x16x4 kernels
+    wrapped-diagonal layout (LIC360_EC=6; the default encode kernel is the 16x16x4 one, whose last layer builds the CDF records in its epilogue --
+    LIC360_EC_FUSE=0 keeps the separate table kernel) and the generic 16x16x4 kernels
     (LIC360_FUSED_CONV=16) produce the same bitstreams.  The switches are read once, when a codec is created."""
     from lic360_fused import FusedCodec
     rng = np.random.default_rng(seed)
@@ -118,7 +119,7 @@ def test_fused_codec_previous_generation_kernels(monkeypatch, G, H, W, B, seed):
     code = np.concatenate([it[0] for it in items], 0)
     mask = np.concatenate([it[1] for it in items], 0)
     ref = [rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G) for i in range(B)]
-    for env in ({"LIC360_DC4": "3", "LIC360_EC4": "3"}, {"LIC360_EC": "6"}, {"LIC360_FUSED_CONV": "16"}):
+    for env in ({"LIC360_DC4": "3", "LIC360_EC4": "3"}, {"LIC360_EC": "6"}, {"LIC360_EC_FUSE": "0"}, {"LIC360_FUSED_CONV": "16"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         fc = FusedCodec(G, H, W, max_batch=B)
