@@ -28,12 +28,15 @@ LIC360_API int lic360_version(void) { return 100; }
 // source coordinate of padded cell (ph,pw): longitude wrap, pole rows reflected + mirrored
 // (extension/sphere_pad_cuda.cu:33-43)
 __device__ __forceinline__ void sphere_src(int ph, int pw, int H, int W, int pad, int &th, int &tw) {
+    // closed forms of  tw = (tw + W) % W;  th = (2H-1-th) % H;  tw = (2W-1-tw) % W  for pad <= min(H, W) (every entry point checks it):
+    // no integer division per cell
     th = ph - pad;
     tw = pw - pad;
-    tw = (tw + W) % W;
+    if (tw < 0) tw += W;
+    if (tw >= W) tw -= W;
     if (th < 0 || th >= H) {
-        th = (2 * H - 1 - th) % H;
-        tw = (2 * W - 1 - tw) % W;
+        th = th < 0 ? -1 - th : 2 * H - 1 - th;
+        tw = W - 1 - tw;
     }
 }
 
@@ -100,9 +103,75 @@ __global__ void k_sphere_lat_scale(const float *__restrict__ in, const float *__
     }
 }
 
+// Plane-per-workgroup forms (blockIdx.x = plane chunk, blockIdx.y = plane): 32-bit index arithmetic only -- the grid-stride forms
+// above spend most of their time in 64-bit div/mod -- and 16-byte accesses along W where rows are 16-byte aligned.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_sphere_pad_plane(const float *__restrict__ in, float *__restrict__ out, int H, int W, int Ho, int Wo, int pad) {
+    const float *ip = in + (long)blockIdx.y * H * W;
+    float *op = out + (long)blockIdx.y * Ho * Wo;
+    const int cells = Ho * Wo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cells; i += gridDim.x * 256) {
+        const int ph = i / Wo, pw = i - ph * Wo;
+        int th, tw;
+        sphere_src(ph, pw, H, W, pad, th, tw);
+        op[i] = ip[th * W + tw];
+    }
+}
+__global__ __launch_bounds__(256) void k_sphere_pad_inplace_plane(float *__restrict__ x, int per_plane, int Hp, int Wp, int pad) {
+    float *xp = x + (long)blockIdx.y * Hp * Wp;
+    const int H = Hp - 2 * pad, W = Wp - 2 * pad;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < per_plane; a += gridDim.x * 256) {
+        int ph, pw, th, tw;
+        apron_cell(a, Hp, Wp, pad, ph, pw);
+        sphere_src(ph, pw, H, W, pad, th, tw);
+        xp[ph * Wp + pw] = xp[(th + pad) * Wp + tw + pad];                      // source is always interior
+    }
+}
+// zero the apron: the 2*pad full rows as 16-byte stores (Wp % 4 == 0 keeps every row 16-byte aligned), the side columns per row
+__global__ __launch_bounds__(256) void k_sphere_trim_plane(float *__restrict__ x, int Hp, int Wp, int pad, int vec) {
+    float *xp = x + (long)blockIdx.y * Hp * Wp;
+    const int H = Hp - 2 * pad;
+    if (vec) {
+        const int q = Wp / 4, nq = 2 * pad * q;
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = threadIdx.x; i < nq; i += 256) {
+            const int r = i / q, c = i - r * q, ph = r < pad ? r : Hp - 2 * pad + r;
+            *(f4 *)(xp + ph * Wp + 4 * c) = z;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * pad * Wp; i += 256) {
+            const int r = i / Wp, c = i - r * Wp, ph = r < pad ? r : Hp - 2 * pad + r;
+            xp[ph * Wp + c] = 0.0f;
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * pad * H; i += 256) {
+        const int r = i / (2 * pad), c = i - r * 2 * pad;
+        xp[(pad + r) * Wp + (c < pad ? c : Wp - 2 * pad + c)] = 0.0f;
+    }
+}
+__global__ __launch_bounds__(256) void k_sphere_cut_edge_plane(const float *__restrict__ in, float *__restrict__ out, int H, int W, int Ho, int Wo, int pad) {
+    const float *ip = in + (long)blockIdx.y * H * W + pad * W + pad;
+    float *op = out + (long)blockIdx.y * Ho * Wo;
+    const int cells = Ho * Wo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cells; i += gridDim.x * 256) {
+        const int ph = i / Wo, pw = i - ph * Wo;
+        op[i] = ip[ph * W + pw];
+    }
+}
+static inline unsigned plane_chunks(long cells, int nc) {          // enough workgroups per plane to fill the chip when planes are few
+    long per = (cells + 255) / 256, want = (256L * 16 + nc - 1) / nc;
+    long g = per < want ? per : want;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
 LIC360_API int lic360_sphere_pad(void *stream, const float *x, float *out, int nc, int h, int w, int pad) {
     ARG_CHECK(x && out && nc > 0 && h > 0 && w > 0 && pad >= 0 && pad <= h && pad <= w);
     int Ho = h + 2 * pad, Wo = w + 2 * pad;
+    if (nc <= 65535 && (long)Ho * Wo < (1l << 30)) {
+        hipLaunchKernelGGL(k_sphere_pad_plane, dim3(plane_chunks((long)Ho * Wo, nc), nc), dim3(256), 0, (hipStream_t)stream, x, out, h, w, Ho, Wo, pad);
+        LAUNCH_CHECK();
+        return 0;
+    }
     long total = (long)nc * Ho * Wo;
     hipLaunchKernelGGL(k_sphere_pad, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, out, total, h, w, Ho, Wo, pad);
     LAUNCH_CHECK();
@@ -113,6 +182,11 @@ LIC360_API int lic360_sphere_pad_inplace(void *stream, float *x, int nc, int hp,
     if (pad == 0) return 0;
     int per_plane = 2 * pad * wp + 2 * pad * (hp - 2 * pad);
     long total = (long)nc * per_plane;
+    if (nc <= 65535 && (long)hp * wp < (1l << 30)) {
+        hipLaunchKernelGGL(k_sphere_pad_inplace_plane, dim3(plane_chunks(per_plane, nc), nc), dim3(256), 0, (hipStream_t)stream, x, per_plane, hp, wp, pad);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_sphere_pad_inplace, dim3(lic360_blocks(total, 2)), dim3(256), 0, (hipStream_t)stream, x, total, per_plane, hp, wp, pad);
     LAUNCH_CHECK();
     return 0;
@@ -126,6 +200,12 @@ LIC360_API int lic360_sphere_trim(void *stream, float *x, int nc, int h, int w, 
     }
     int per_plane = 2 * pad * w + 2 * pad * (h - 2 * pad);
     long total = (long)nc * per_plane;
+    if (nc <= 65535 && (long)h * w < (1l << 30)) {
+        const int vec = (w % 4 == 0) && (((uintptr_t)x & 15) == 0);
+        hipLaunchKernelGGL(k_sphere_trim_plane, dim3(1, nc), dim3(256), 0, (hipStream_t)stream, x, h, w, pad, vec);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_sphere_trim, dim3(lic360_blocks(total, 2)), dim3(256), 0, (hipStream_t)stream, x, total, per_plane, h, w, pad);
     LAUNCH_CHECK();
     return 0;
@@ -134,6 +214,11 @@ LIC360_API int lic360_sphere_cut_edge(void *stream, const float *x, float *out, 
     ARG_CHECK(x && out && nc > 0 && pad >= 0 && h > 2 * pad && w > 2 * pad);
     int Ho = h - 2 * pad, Wo = w - 2 * pad;
     long total = (long)nc * Ho * Wo;
+    if (nc <= 65535 && (long)h * w < (1l << 30)) {
+        hipLaunchKernelGGL(k_sphere_cut_edge_plane, dim3(plane_chunks((long)Ho * Wo, nc), nc), dim3(256), 0, (hipStream_t)stream, x, out, h, w, Ho, Wo, pad);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_sphere_cut_edge, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, out, total, h, w, Ho, Wo, pad);
     LAUNCH_CHECK();
     return 0;
@@ -281,13 +366,91 @@ __global__ void k_dquant(const float *__restrict__ in, const float *__restrict__
         out[i] = mask[i] > 0 ? wc[tc * levels + id] : wc[tc * levels];
     }
 }
+// plane (n, c) on blockIdx.y: the channel's centre table sits in registers, 16 bytes per lane along the plane
+__global__ __launch_bounds__(256) void k_dquant_plane4(const float *__restrict__ in, const float *__restrict__ mask, const float *__restrict__ wc,
+                                                       float *__restrict__ out, int inner4, int C, int levels) {
+    const int tc = blockIdx.y % C;
+    const float *w = wc + tc * levels;
+    const float w0 = w[0];
+    const long base = (long)blockIdx.y * inner4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < inner4; i += gridDim.x * 256) {
+        const f4 v = ((const f4 *)in)[base + i], m = ((const f4 *)mask)[base + i];
+        f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = m[k] > 0 ? w[(int)((double)v[k] + 0.00001)] : w0;                  // dquant_cuda.cu:34-47
+        ((f4 *)out)[base + i] = o;
+    }
+}
+// slab (n, c) per workgroup, 16 bytes per lane; per-thread level counts in 8-bit fields of one 64-bit register (levels <= 8,
+// at most 255 elements per thread between flushes), one LDS atomic per (thread, flush) and one global atomic per (slab, level)
+__global__ __launch_bounds__(256) void k_quant_slab4(const float *__restrict__ in, const float *__restrict__ wq, float *__restrict__ top,
+                                                     float *__restrict__ qidx, float *__restrict__ count, int inner4, int C, int levels) {
+    __shared__ int hist[8];
+    const int pc = blockIdx.x % C;
+    if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const float *wl = wq + pc * levels;                                    // 8 floats, L1-resident (a register copy would be indexed dynamically)
+    const long base = (long)blockIdx.x * inner4;
+    unsigned long long pk = 0;
+    int since = 0;
+    // per-thread 8-bit fields -> two registers of 16-bit fields, summed over the wave with 6 xor-shuffles, then 8 LDS atomics
+    // per wave (64 x 255 < 2^16)
+    auto flush = [&]() {
+        unsigned long long lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            lo |= ((pk >> (8 * b)) & 0xffull) << (16 * b);
+            hi |= ((pk >> (8 * (b + 4))) & 0xffull) << (16 * b);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            lo += __shfl_xor(lo, m);
+            hi += __shfl_xor(hi, m);
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c0 = (int)((lo >> (16 * b)) & 0xffffull), c1 = (int)((hi >> (16 * b)) & 0xffffull);
+                if (c0) atomicAdd(&hist[b], c0);
+                if (c1) atomicAdd(&hist[b + 4], c1);
+            }
+        }
+        pk = 0;
+        since = 0;
+    };
+    for (int i0 = 0; i0 < inner4; i0 += 256) {                            // uniform trip count: flush() shuffles across the wave
+        const int i = i0 + threadIdx.x;
+        if (i < inner4) {
+            const f4 v = ((const f4 *)in)[base + i];
+            f4 t, q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float tt;
+                const int j = lic360_quant_one(v[k], wl, levels, &tt);
+                t[k] = tt;
+                q[k] = (float)j;
+                pk += 1ull << (8 * j);
+            }
+            ((f4 *)top)[base + i] = t;
+            if (qidx) ((f4 *)qidx)[base + i] = q;
+        }
+        since += 4;
+        if (since > 250) flush();
+    }
+    flush();
+    __syncthreads();
+    if (threadIdx.x < levels && hist[threadIdx.x]) atomicAdd(count + pc * levels + threadIdx.x, -(float)hist[threadIdx.x]);   // quant_cuda.cu:56,74
+}
 LIC360_API int lic360_quant(void *stream, const float *x, const float *weight_b, float *wq, float *top, float *qidx, float *count,
                             int n, int c, int h, int w, int levels) {
     ARG_CHECK(x && weight_b && wq && top && count && n > 0 && c > 0 && levels > 0);
     long inner = (long)h * w, total = (long)n * c * inner;
     HIP_TRY(hipMemsetAsync(count, 0, sizeof(float) * (size_t)c * levels, (hipStream_t)stream));
     hipLaunchKernelGGL(k_quant_weight, dim3(lic360_blocks(c * levels)), dim3(256), 0, (hipStream_t)stream, weight_b, wq, c * levels, levels);
-    if (levels <= 64 && (long)n * c < (1l << 30))
+    const bool al16 = inner % 4 == 0 && (((uintptr_t)x | (uintptr_t)top | (uintptr_t)qidx) & 15) == 0;
+    if (levels <= 8 && al16 && (long)n * c < (1l << 30) && inner / 4 < (1l << 30))
+        hipLaunchKernelGGL(k_quant_slab4, dim3((unsigned)(n * c)), dim3(256), 0, (hipStream_t)stream, x, wq, top, qidx, count, (int)(inner / 4), c, levels);
+    else if (levels <= 64 && (long)n * c < (1l << 30))
         hipLaunchKernelGGL(k_quant_slab, dim3((unsigned)(n * c)), dim3(256), 0, (hipStream_t)stream, x, wq, top, qidx, count, inner, c, levels);
     else
         hipLaunchKernelGGL(k_quant, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, wq, top, qidx, count, total, inner, c, levels);
@@ -299,6 +462,12 @@ LIC360_API int lic360_dquant(void *stream, const float *x, const float *mask, co
     ARG_CHECK(x && mask && weight_b && wc && out && n > 0 && c > 0 && levels > 0);
     long inner = (long)h * w, total = (long)n * c * inner;
     hipLaunchKernelGGL(k_dquant_weight, dim3(lic360_blocks(c)), dim3(256), 0, (hipStream_t)stream, weight_b, wc, c, levels);
+    if (inner % 4 == 0 && (((uintptr_t)x | (uintptr_t)mask | (uintptr_t)out) & 15) == 0 && (long)n * c <= 65535 && inner / 4 < (1l << 30)) {
+        hipLaunchKernelGGL(k_dquant_plane4, dim3(plane_chunks(inner / 4, n * c), n * c), dim3(256), 0, (hipStream_t)stream, x, mask, wc, out,
+                           (int)(inner / 4), c, levels);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_dquant, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, mask, wc, out, total, inner, c, levels);
     LAUNCH_CHECK();
     return 0;
@@ -326,11 +495,49 @@ __global__ void k_wtod(const float *__restrict__ in, float *__restrict__ out, lo
         out[i] = in[((tn * C + tc) * H + ph * s + rc / s) * W + pw * s + rc % s];
     }
 }
+// stride 2, 16 bytes per lane on both sides.  d2w: lane (row h, quad q) of output channel co reads 4 columns of the input
+// channels 4co..4co+3 and writes 8 columns of output rows 2h, 2h+1 (channels 4co, 4co+1 interleaved / 4co+2, 4co+3).
+// wtod is the inverse: 8 columns of input rows 2h, 2h+1 -> 4 columns of 4 output channels.
+template <bool D2W>
+__global__ __launch_bounds__(256) void k_dtow2(const float *__restrict__ in, float *__restrict__ out, int Hs, int Ws4) {
+    // Hs x (4 Ws4): the SMALL plane (d2w: input plane; wtod: output plane); blockIdx.y = n * Co + co with Co small-side channel groups
+    const long small = (long)blockIdx.y * 4 * Hs * Ws4 * 4, big = (long)blockIdx.y * 4 * Hs * Ws4 * 4;
+    const int cells = Hs * Ws4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cells; i += gridDim.x * 256) {
+        const int h = i / Ws4, q = i - h * Ws4;
+        const long so = small + (long)h * Ws4 * 4 + 4 * q, ps = (long)Hs * Ws4 * 4;           // + k * ps for channel k of the group
+        const long bo = big + (long)(2 * h) * Ws4 * 8 + 8 * q, br = (long)Ws4 * 8;             // + br for row 2h + 1
+        if constexpr (D2W) {
+            const f4 a = *(const f4 *)(in + so), b = *(const f4 *)(in + so + ps), c = *(const f4 *)(in + so + 2 * ps), d = *(const f4 *)(in + so + 3 * ps);
+            *(f4 *)(out + bo) = (f4){a[0], b[0], a[1], b[1]};
+            *(f4 *)(out + bo + 4) = (f4){a[2], b[2], a[3], b[3]};
+            *(f4 *)(out + bo + br) = (f4){c[0], d[0], c[1], d[1]};
+            *(f4 *)(out + bo + br + 4) = (f4){c[2], d[2], c[3], d[3]};
+        } else {
+            const f4 r0 = *(const f4 *)(in + bo), r1 = *(const f4 *)(in + bo + 4), r2 = *(const f4 *)(in + bo + br), r3 = *(const f4 *)(in + bo + br + 4);
+            *(f4 *)(out + so) = (f4){r0[0], r0[2], r1[0], r1[2]};
+            *(f4 *)(out + so + ps) = (f4){r0[1], r0[3], r1[1], r1[3]};
+            *(f4 *)(out + so + 2 * ps) = (f4){r2[0], r2[2], r3[0], r3[2]};
+            *(f4 *)(out + so + 3 * ps) = (f4){r2[1], r2[3], r3[1], r3[3]};
+        }
+    }
+}
 LIC360_API int lic360_dtow(void *stream, const float *x, float *out, int n, int c, int h, int w, int stride, int d2w) {
     ARG_CHECK(x && out && n > 0 && stride > 0);
     if (d2w) ARG_CHECK(c % (stride * stride) == 0);
     else ARG_CHECK(h % stride == 0 && w % stride == 0);
     long total = (long)n * c * h * w;
+    if (stride == 2 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+        // small-side plane: d2w -> the input plane [h, w] (w % 4 == 0); wtod -> the output plane [h/2, w/2] (w % 8 == 0)
+        const int Hs = d2w ? h : h / 2, Ws = d2w ? w : w / 2, groups = d2w ? n * (c / 4) : n * c;
+        if (Ws % 4 == 0 && groups <= 65535 && (long)Hs * Ws < (1l << 28)) {
+            const dim3 grid(plane_chunks((long)Hs * (Ws / 4), groups), groups);
+            if (d2w) hipLaunchKernelGGL(k_dtow2<true>, grid, dim3(256), 0, (hipStream_t)stream, x, out, Hs, Ws / 4);
+            else hipLaunchKernelGGL(k_dtow2<false>, grid, dim3(256), 0, (hipStream_t)stream, x, out, Hs, Ws / 4);
+            LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (d2w) hipLaunchKernelGGL(k_dtow, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, out, total, c, h, w, stride);
     else hipLaunchKernelGGL(k_wtod, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, out, total, c, h, w, stride);
     LAUNCH_CHECK();
