@@ -294,10 +294,20 @@ LIC360_API int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *p,
                                         const float *act, const float *residual, float *out, int n, int h, int w, int nb,
                                         const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum,
                                         int x_mod, int skewed) {
-    ARG_CHECK(p && x && packed && bias && out && idx_dev && plane_idx_dev && plane_idx_host && n > 0 && nb > 0 && n % nb == 0);
-    ARG_CHECK(x_mod > 0 && x_mod <= n);
     // activation layout: NCHW, or diagonal-major [n][c][s=th+tw][th] (positions of one anti-diagonal contiguous)
     long cs = skewed ? (long)(h + w - 1) * h : (long)h * w, hs = skewed ? h + 1 : w, ws = skewed ? h : 1;
+    return lic360_cconv_dc_plane_strided(stream, p, x, packed, bias, act, residual, out, n, h, w, nb, idx_dev, plane_idx_dev, plane_idx_host,
+                                         psum, x_mod, cs, hs, ws, cs, hs, ws);
+}
+
+// internal (hidden visibility): explicit strides -- cell (th, tw) of plane c of sample n at [(n*C + c)*cs + th*hs + tw*ws] from the
+// pointer passed (the caller adds a layout's constant offset to x / residual / out); residual uses the output strides
+int lic360_cconv_dc_plane_strided(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
+                                  const float *act, const float *residual, float *out, int n, int h, int w, int nb,
+                                  const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod,
+                                  long x_cs, long x_hs, long x_ws, long o_cs, long o_hs, long o_ws) {
+    ARG_CHECK(p && x && packed && bias && out && idx_dev && plane_idx_dev && plane_idx_host && n > 0 && nb > 0 && n % nb == 0);
+    ARG_CHECK(x_mod > 0 && x_mod <= n);
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
     // widest tile range on this plane -> grid.x (blocks past a tile's range exit immediately)
     int maxpos = 0;
@@ -313,7 +323,7 @@ LIC360_API int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *p,
     dim3 grid((maxpos + 15) / 16, p->n_mtiles, n);
     hipLaunchKernelGGL(k_cconv_dc, grid, dim3(512), 0, (hipStream_t)stream, x, packed, bias, act, out, p->d_mt_rec_start, p->d_leaf_cnt,
                        p->d_term, p->d_mt_glo, p->d_mt_ghi, idx_dev, plane_idx_dev, p->C, h, w, p->nout, p->cout, p->half, n / nb,
-                       lic360_conv_plan_packed_floats(p), psum, residual, x_mod, cs, hs, ws, cs, hs, ws);
+                       lic360_conv_plan_packed_floats(p), psum, residual, x_mod, x_cs, x_hs, x_ws, o_cs, o_hs, o_ws);
     LAUNCH_CHECK();
     return 0;
 }

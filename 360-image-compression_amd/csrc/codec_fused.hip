@@ -535,12 +535,27 @@ struct lic360_impcodec {
     float *e_x0, *e_buf[3];
     uint2 *e_rec;
     float *d_x0, *d_act[11], *d_y;
+    // leaf-resident 16x16x4 kernels for the 144-channel layers (csrc/cconv144_kernels.hip): encode on zero-haloed NCHW planes,
+    // decode on zero-padded diagonal-major planes [rows = sk_rows][sk_pitch], cell (th, tw) at (th + tw + sk_row0, th + sk_col0)
+    bool use144 = false;
+    float *packed144[12];
+    int e_hp = 0, e_wp = 0;
+    float *e_pad[3] = {nullptr, nullptr, nullptr}, *e_plain = nullptr;
+    int sk_rows, sk_pitch, sk_row0, sk_col0;
     int *d_tab;                                 // [maxB][tab_pitch][IMP_TW] tables of the current plane
     int tab_pitch;
     AcDevState *d_state;
 };
 #define IMP_TW 64                              // ints per table row (nsym + 1 <= 64), one per lane
 
+// plain NCHW planes -> interior of zero-haloed planes [hp][wp] (cell (r, c) at (r + 2, c + 2))
+__global__ void k_imp_halo(const float *__restrict__ in, float *__restrict__ out, long total, int H, int W, int hp, int wp) {
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % W), r = (int)((i / W) % H);
+        const long pl = i / ((long)H * W);
+        out[pl * hp * wp + (long)(r + 2) * wp + c + 2] = in[i];
+    }
+}
 __global__ void k_imp_prep(const float *__restrict__ lv, float *__restrict__ x0, long total, float sc) {
     GRID_STRIDE(i, total) x0[i] = lic360_affine(lv[i], sc, -1.0f);                 // Scale(-1, 2/47): lic360_demo.py:168
 }
@@ -566,13 +581,14 @@ __global__ void k_imp_enc_tables(const float *__restrict__ y, const float *__res
 // decode activations are diagonal-major [n][c][H+W-1][H] (cell (th, tw) at (th+tw)*H + th): the 16 plane positions a
 // conv wave gathers are contiguous
 __global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__ y, const int *__restrict__ idx, int start, int len,
-                                                       int *__restrict__ tab, int tab_pitch, int H, int W, int nsym) {
+                                                       int *__restrict__ tab, int tab_pitch, int H, int W, int nsym,
+                                                       int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
     const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
     if (i >= len) return;
-    const long HW = (long)H * W, SK = (long)(H + W - 1) * H;
+    const long HW = (long)H * W, SK = (long)sk_rows * sk_pitch;
     const int th = idx[start + i], tw = idx[start + i + HW];
     float T[65];
-    imp_table(y, (long)b * nsym * SK + (long)(th + tw) * H + th, SK, nsym, T);
+    imp_table(y, (long)b * nsym * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0, SK, nsym, T);
     int *row = tab + ((long)b * tab_pitch + i) * IMP_TW;
     for (int k = 0; k <= nsym; ++k) row[k] = (int)T[k];
 }
@@ -581,7 +597,7 @@ template <bool LINEAR>
 __global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ tab, int tab_pitch, const int *__restrict__ idx, int start, int len,
                                                       AcDevState *__restrict__ state, const uint8_t *__restrict__ bytes, long cap,
                                                       const int *__restrict__ nbytes, float *__restrict__ x0, float *__restrict__ out,
-                                                      int H, int W, int nsym, float sc) {
+                                                      int H, int W, int nsym, float sc, int sk_rows = 0, int sk_pitch = 0, int sk_row0 = 0, int sk_col0 = 0) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const long HW = (long)H * W;
     AcDevState ds = state[b];
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ ta
             if constexpr (LINEAR) out[(long)b * HW + start + j] = (float)sym;
             else {
                 const int th = idx[start + j], tw = idx[start + j + HW];
-                x0[(long)b * (H + W - 1) * H + (long)(th + tw) * H + th] = lic360_affine((float)sym, sc, -1.0f);   // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
+                x0[(long)b * sk_rows * sk_pitch + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0] = lic360_affine((float)sym, sc, -1.0f);   // TileInput(1, -1, 2/47, 1): lic360_demo.py:264
                 out[(long)b * HW + (long)th * W + tw] = (float)sym;
             }
         }
@@ -622,7 +638,7 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
     memset(c->layer_set, 0, sizeof(c->layer_set));
     c->H = h; c->W = w; c->HW = h * w; c->P = h + w - 1; c->cpg = hidden_channels; c->nsym = nsym; c->maxB = max_batch;
     c->sc = 2.0f / (float)(nsym - 2);
-    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = nullptr;
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed144[i] = nullptr;
     int rc = 0;
     rc |= lic360_conv_plan_create(1, 1, hidden_channels, 5, 5, &c->plan[0]);
     rc |= lic360_conv_plan_create(hidden_channels, 1, hidden_channels, 5, 6, &c->plan[1]);
@@ -638,7 +654,17 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
     rc |= dmalloc(&c->e_x0, B * HW);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], B * CE * HW);
     rc |= dmalloc(&c->e_rec, B * HW);
-    const size_t SK = (size_t)(h + w - 1) * h;                            // diagonal-major decode planes
+    // 144-channel layers on the leaf-resident 16x16x4 kernels (LIC360_IMP144=0 keeps the generic kernels: A/B runs)
+    { const char *f = getenv("LIC360_IMP144"); c->use144 = lic360_conv144_supported(c->plan[1]) && lic360_conv144_supported(c->plan[2]) && h <= 32 && !(f && f[0] == '0'); }
+    if (c->use144) {
+        if (lic360_ec144_layout(h, w, &c->e_hp, &c->e_wp) || lic360_dc144_layout(h, w, &c->sk_rows, &c->sk_pitch)) return 1;
+        c->sk_row0 = 4; c->sk_col0 = 2;
+        for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_pad[i], B * C * (size_t)c->e_hp * c->e_wp);
+        rc |= dmalloc(&c->e_plain, B * CE * HW);
+        if (rc) return 1;
+        for (int i = 0; i < 3; ++i) HIP_TRY(hipMemset(c->e_pad[i], 0, B * C * (size_t)c->e_hp * c->e_wp * 4));   // the halo stays zero
+    } else { c->sk_rows = h + w - 1; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
+    const size_t SK = (size_t)c->sk_rows * c->sk_pitch;                   // diagonal-major decode planes
     rc |= dmalloc(&c->d_x0, B * SK);
     for (int i = 0; i < 11; ++i) rc |= dmalloc(&c->d_act[i], B * C * SK);
     rc |= dmalloc(&c->d_y, B * (size_t)nsym * SK);
@@ -656,7 +682,9 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
 LIC360_API void lic360_impcodec_destroy(lic360_impcodec *c) {
     if (!c) return;
     for (int i = 0; i < 3; ++i) lic360_conv_plan_destroy(c->plan[i]);
-    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); }
+    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); (void)hipFree(c->packed144[i]); }
+    for (int i = 0; i < 3; ++i) (void)hipFree(c->e_pad[i]);
+    (void)hipFree(c->e_plain);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->e_x0);
     for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0);
@@ -674,6 +702,10 @@ LIC360_API int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int l
         if (act && dmalloc(&c->act[layer], (size_t)p->nout)) return 1;
     }
     if (lic360_conv_pack(stream, p, weight, 1, c->packed[layer])) return 1;
+    if (c->use144 && layer > 0) {
+        if (!c->packed144[layer] && dmalloc(&c->packed144[layer], (size_t)lic360_conv144_packed_floats(p))) return 1;
+        if (lic360_conv144_pack(stream, p, weight, c->packed144[layer])) return 1;
+    }
     HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->layer_set[layer] = true;
@@ -693,6 +725,29 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
     const long total = (long)B * c->HW;
     hipLaunchKernelGGL(k_imp_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, levels, c->e_x0, total, c->sc);
     LAUNCH_CHECK();
+    if (c->use144) {
+        // layer 0 (1 -> 144) on the generic kernel into plain NCHW, copied into the zero-haloed planes; layers 1..10 haloed -> haloed;
+        // layer 11 (144 -> nsym) haloed -> plain NCHW for the table kernel
+        const long PLh = (long)c->e_hp * c->e_wp;
+        if (lic360_cconv_ec_ex(stream, c->plan[0], c->e_x0, c->packed[0], c->bias[0], c->act[0], nullptr, c->e_plain, B, H, W, 1, B)) return 1;
+        hipLaunchKernelGGL(k_imp_halo, dim3(lic360_blocks((long)B * c->cpg * c->HW, 4)), dim3(256), 0, s, c->e_plain, c->e_pad[0], (long)B * c->cpg * c->HW, H, W, c->e_hp, c->e_wp);
+        LAUNCH_CHECK();
+        float *cur = c->e_pad[0], *t1 = c->e_pad[1], *nxt = c->e_pad[2];
+        auto ec = [&](int layer, const float *xin, const float *res, float *dst) -> int {
+            return lic360_cconv144_ec(stream, c->plan[1], xin, c->packed144[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, PLh, c->e_wp, 2);
+        };
+        for (int blk = 0; blk < 5; ++blk) {
+            if (ec(1 + 2 * blk, cur, nullptr, t1)) return 1;
+            if (ec(2 + 2 * blk, t1, cur, nxt)) return 1;
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (lic360_cconv144_ec(stream, c->plan[2], cur, c->packed144[11], c->bias[11], nullptr, nullptr, c->e_plain, B, H, W, (long)c->HW, W, 0)) return 1;
+        hipLaunchKernelGGL(k_imp_enc_tables, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, c->e_plain, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
+        LAUNCH_CHECK();
+        return 0;
+    }
     float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
     auto ec = [&](int layer, const float *xin, const float *res, float *dst) -> int {
         return lic360_cconv_ec_ex(stream, c->plan[plan_of(layer)], xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, 1, B);
@@ -719,9 +774,14 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
     hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
     LAUNCH_CHECK();
     const int *pih = c->h_pidx.data();
+    const long SK = (long)c->sk_rows * c->sk_pitch, off0 = (long)c->sk_row0 * c->sk_pitch + c->sk_col0;
     auto dc = [&](int layer, const float *xin, const float *res, float *dst, int p) -> int {
-        return lic360_cconv_dc_plane_ex(stream, c->plan[plan_of(layer)], xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, 1,
-                                        c->d_idx, c->d_pidx, pih, p, B, 1);
+        if (c->use144 && layer > 0)
+            return lic360_cconv144_dc_plane(stream, c->plan[plan_of(layer)], xin, c->packed144[layer], c->bias[layer], c->act[layer], res, dst, B, H, W, p);
+        // generic kernel on the diagonal-major planes: cell (th, tw) at th * (pitch + 1) + tw * pitch from the layout's origin
+        return lic360_cconv_dc_plane_strided(stream, c->plan[plan_of(layer)], xin + off0, c->packed[layer], c->bias[layer], c->act[layer],
+                                             res ? res + off0 : nullptr, dst + off0, B, H, W, 1, c->d_idx, c->d_pidx, pih, p, B,
+                                             SK, c->sk_pitch + 1, c->sk_pitch, SK, c->sk_pitch + 1, c->sk_pitch);
     };
     for (int p = 0; p < c->P; ++p) {
         if (dc(0, c->d_x0, nullptr, c->d_act[0], p)) return 1;
@@ -733,10 +793,11 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
         if (dc(11, c->d_act[10], nullptr, c->d_y, p)) return 1;
         const int start = pih[p], len = pih[p + 1] - pih[p];
         if (len <= 0) continue;
-        hipLaunchKernelGGL(k_imp_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym);
+        hipLaunchKernelGGL(k_imp_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
+                           c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_imp_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
-                           c->d_x0, levels_out, H, W, c->nsym, c->sc);
+                           c->d_x0, levels_out, H, W, c->nsym, c->sc, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);

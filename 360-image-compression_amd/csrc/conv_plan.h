@@ -23,3 +23,7 @@ static const int LIC360_REC_PAD = 4;       // records readable past the end (sof
 int lic360_cconv4_dc_plane_mode(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                 const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod, int mode);
 int lic360_dc4_env_mode(void);
+int lic360_cconv_dc_plane_strided(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
+                                  const float *act, const float *residual, float *out, int n, int h, int w, int nb,
+                                  const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod,
+                                  long x_cs, long x_hs, long x_ws, long o_cs, long o_hs, long o_ws);

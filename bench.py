@@ -58,6 +58,7 @@ def parse_args():
                     "decode wavefront wide enough to fill 256 CUs (BASELINE.json configs[3] is the 8-per-GPU form: see `config4`)")
     ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
                     "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
+    ap.add_argument("--imp-streams", type=int, default=1, help="1: the importance-map codecs run on HIP streams of their own; 0: on their sub-batch's stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip latent-only pass, single image, config4, streaming ops)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch / sharding / reporting path on gloo: no codec work, value 0")
@@ -140,7 +141,7 @@ def run_rank(args):
     ns = max(1, min(args.streams, B))
     sizes = [B // ns + (1 if i < B % ns else 0) for i in range(ns)]
     code_np, mask_np, level_np = synth_latents(B, seed0=1000 * rank)
-    codecs, icodecs, codes, masks, levels, streams = [], [], [], [], [], []
+    codecs, icodecs, codes, masks, levels, streams, istreams = [], [], [], [], [], [], []
     o = 0
     for sz in sizes:
         c = FusedCodec(G, H, W, max_batch=sz, device=local)
@@ -153,22 +154,27 @@ def run_rank(args):
         masks.append(torch.from_numpy(mask_np[o:o + sz]).to(dev))
         levels.append(torch.from_numpy(level_np[o:o + sz]).to(dev))
         streams.append(torch.cuda.Stream(device=dev))
+        # the importance-map codec of a sub-batch runs on a stream of its own: the two bitstreams of an image are independent,
+        # and its small kernels fill the gaps the latent codec's launches leave
+        istreams.append(torch.cuda.Stream(device=dev) if args.imp_streams else streams[-1])
         o += sz
     torch.cuda.synchronize(dev)
 
     def run(cds, mks, lvs, imp=True):
         """encode then decode of one list of sub-batches (one per stream); inputs resident in HBM, bitstreams stay in HBM"""
-        for c, ic, cd, mk, lv, st in zip(codecs, icodecs, cds, mks, lvs, streams):
+        for c, ic, cd, mk, lv, st, ist in zip(codecs, icodecs, cds, mks, lvs, streams, istreams):
             if cd.shape[0]:
-                with torch.cuda.stream(st):
-                    if imp:
+                if imp:
+                    with torch.cuda.stream(ist):
                         ic.encode_async(lv)
-                    c.encode_async(cd, mk)
-        for c, ic, cd, mk, lv, st in zip(codecs, icodecs, cds, mks, lvs, streams):
-            if cd.shape[0]:
                 with torch.cuda.stream(st):
-                    if imp:
+                    c.encode_async(cd, mk)
+        for c, ic, cd, mk, lv, st, ist in zip(codecs, icodecs, cds, mks, lvs, streams, istreams):
+            if cd.shape[0]:
+                if imp:
+                    with torch.cuda.stream(ist):
                         ic.decode_async(lv.shape[0])
+                with torch.cuda.stream(st):
                     c.decode_async(mk, cd.shape[0])
 
     def exact(cds, mks, lvs, imp=True):

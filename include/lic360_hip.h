@@ -176,6 +176,22 @@ int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *plan, const f
                              const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
                              void *rec, int images, int h, int w, int *ctr);
 
+/* The importance-map net's hidden / last layers (one group, C = 144, constrain 6: test/lic360_demo.py:153-161, 254-262) on
+ * v_mfma_f32_16x16x4_f32 (csrc/cconv144_kernels.hip): same results bit for bit as lic360_cconv_ec / lic360_cconv_dc_plane.
+ * Encode order: x = zero-haloed NCHW planes [n][144][hp][wp] (lic360_ec144_layout, cell (r, c) at [(r+2)*wp + c+2]); out /
+ * residual = [n][nout] planes with stride oplane, rows of opitch floats, cell (r, c) at [(r+ooff)*opitch + c+ooff] (ooff 2 =
+ * the same haloed layout, 0 = plain NCHW).  Decode order (plane = anti-diagonal s of every map, h <= 32): x / residual / out are
+ * zero-padded diagonal-major planes [n][c][rows][pitch] (lic360_dc144_layout), cell (th, tw) at [(th+tw+4)*pitch + th+2]. */
+int lic360_conv144_supported(const lic360_conv_plan *plan);
+long lic360_conv144_packed_floats(const lic360_conv_plan *plan);
+int lic360_conv144_pack(void *stream, const lic360_conv_plan *plan, const float *weight, float *packed144);
+int lic360_ec144_layout(int h, int w, int *hp, int *wp);
+int lic360_cconv144_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed144, const float *bias,
+                       const float *act, const float *residual, float *out, int n, int h, int w, long oplane, int opitch, int ooff);
+int lic360_dc144_layout(int h, int w, int *rows, int *pitch);
+int lic360_cconv144_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed144, const float *bias,
+                             const float *act, const float *residual, float *out, int n, int h, int w, int s);
+
 /* ---- A19/A20 arithmetic coder (host side, as in the reference) ----------------------------- */
 /* Coder operates on HOST int32 tables exactly like the reference's Coder (extension/coder.h:10-63,
  * extension/coder.cpp:30-113): the op API hands it CPU tensors. */

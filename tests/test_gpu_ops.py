@@ -495,3 +495,83 @@ def test_cconv16_ec_bit_exact(lic, case):
     got = host(out)
     L.lic360_conv_plan_destroy(plan)
     assert np.array_equal(got, pad(ref)), "max abs diff %g" % np.abs(got - pad(ref)).max()
+
+
+# ------------------------------------------------------------------ importance-map net layers (one group, C = 144) on 16x16x4 MFMAs
+def _i144_setup(lic, rng, nout, act):
+    import ctypes as C
+    w, b, a = conv_params(rng, None, nout, 144, act=act)
+    L = lic._lib
+    plan = C.c_void_p(0)
+    assert L.lic360_conv_plan_create(144, 1, nout, 5, 6, C.byref(plan)) == 0
+    assert L.lic360_conv144_supported(plan) == 1
+    packed = torch.empty(L.lic360_conv144_packed_floats(plan), dtype=torch.float32, device="cuda:0")
+    wd = dev(w)
+    assert L.lic360_conv144_pack(lic._stream(0), plan, lic._p(wd), lic._p(packed)) == 0, L.lic360_last_error()
+    return w, b, a, plan, packed
+
+
+@pytest.mark.parametrize("case", [(2, 7, 21, 144, True, 2), (1, 4, 6, 49, False, 0), (3, 32, 64, 144, True, 2), (1, 1, 1, 20, True, 0), (1, 33, 17, 49, False, 0)],
+                         ids=lambda c: "n%d_%dx%d_to%d" % c[:4])
+def test_cconv144_ec_bit_exact(lic, case):
+    """lic360_cconv144_ec (hidden / last layers of the importance-map net) == oracle; output into the haloed layout or plain NCHW"""
+    import ctypes as C
+    N, H, W, nout, act, ooff = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    w, b, a, plan, packed = _i144_setup(lic, rng, nout, act)
+    x = rng.standard_normal((N, 144, H, W)).astype(np.float32)
+    x[rng.random(x.shape) < 0.1] = 0.0
+    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
+    ref = orc.cconv_ec(x, w, b, a, 1, 6) + res
+    L = lic._lib
+    hp, wp = C.c_int(), C.c_int()
+    assert L.lic360_ec144_layout(H, W, C.byref(hp), C.byref(wp)) == 0
+    hp, wp = hp.value, wp.value
+    pad = lambda t: np.pad(t, ((0, 0), (0, 0), (2, hp - H - 2), (2, wp - W - 2)))
+    xd, bd = dev(pad(x)), dev(b)
+    ad = dev(a) if act else None
+    if ooff:
+        rd, out, oplane, opitch = dev(pad(res)), torch.zeros((N, nout, hp, wp), dtype=torch.float32, device="cuda:0"), hp * wp, wp
+    else:
+        rd, out, oplane, opitch = dev(res), torch.zeros((N, nout, H, W), dtype=torch.float32, device="cuda:0"), H * W, W
+    P = lic._p
+    assert L.lic360_cconv144_ec(lic._stream(0), plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, oplane, opitch, ooff) == 0, L.lic360_last_error()
+    got = host(out)
+    L.lic360_conv_plan_destroy(plan)
+    want = pad(ref) if ooff else ref
+    assert np.array_equal(got, want), "max abs diff %g" % np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("case", [(2, 6, 9, 144, True), (1, 32, 64, 49, False), (3, 5, 3, 144, True), (2, 32, 7, 144, True)], ids=lambda c: "n%d_%dx%d_to%d" % c[:4])
+def test_cconv144_dc_planes_bit_exact(lic, case):
+    """decode order on the zero-padded diagonal-major layout: after every plane the persistent output equals the oracle's"""
+    import ctypes as C
+    N, H, W, nout, act = case
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    w, b, a, plan, packed = _i144_setup(lic, rng, nout, act)
+    x = rng.standard_normal((N, 144, H, W)).astype(np.float32)
+    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
+    L = lic._lib
+    rows, pitch = C.c_int(), C.c_int()
+    assert L.lic360_dc144_layout(H, W, C.byref(rows), C.byref(pitch)) == 0
+    rows, pitch = rows.value, pitch.value
+    th, tw = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+
+    def skew(t):
+        o = np.zeros(t.shape[:2] + (rows, pitch), np.float32)
+        o[:, :, th + tw + 4, th + 2] = t
+        return o
+    xd, rd, bd = dev(skew(x)), dev(skew(res)), dev(b)
+    ad = dev(a) if act else None
+    out = torch.zeros((N, nout, rows, pitch), dtype=torch.float32, device="cuda:0")
+    idx, pidx = orc.code_contex(H, W)
+    ref = np.zeros((N, nout, H, W), np.float32)
+    P = lic._p
+    for s in range(H + W - 1):
+        orc.cconv_dc_plane(x, w, b, a, ref, 1, 6, idx, pidx, s)
+        assert L.lic360_cconv144_dc_plane(lic._stream(0), plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, s) == 0, L.lic360_last_error()
+        if s in (0, 3, H - 1, H + W - 2):
+            on = (th + tw <= s)
+            assert np.array_equal(host(out), skew((ref + res) * on)), "plane %d" % s
+    L.lic360_conv_plan_destroy(plan)
+    assert np.array_equal(ref, orc.cconv_ec(x, w, b, a, 1, 6))
