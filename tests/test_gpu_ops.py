@@ -575,3 +575,61 @@ def test_cconv144_dc_planes_bit_exact(lic, case):
             assert np.array_equal(host(out), skew((ref + res) * on)), "plane %d" % s
     L.lic360_conv_plan_destroy(plan)
     assert np.array_equal(ref, orc.cconv_ec(x, w, b, a, 1, 6))
+
+
+@pytest.mark.parametrize("G,B,H,W", [(6, 2, 7, 21), (48, 1, 8, 16), (3, 1, 4, 5)])
+def test_cconv16_last_layer_with_fused_tables(lic, G, B, H, W):
+    """lic360_cconv16_ec_tables (N1: last conv layer + softmax / sigma floor / erf CDF / fix-up / record write in one kernel) ==
+    oracle last layer -> per-plane TileExtractBatch -> EntropyBatchGmmTable -> (T[sym], T[sym+1]) in coding order"""
+    import ctypes as C
+    rng = np.random.default_rng(G * 100 + H)
+    Cc, nout = G * 4, G * 3
+    w, b, _ = conv_params(rng, 3, nout, Cc, act=False)
+    b[1] += 2.0
+    x = (0.5 * rng.standard_normal((3 * B, Cc, H, W))).astype(np.float32)
+    code, mask = [], []
+    for i in range(B):
+        c, m, _ = latent(np.random.default_rng(i), G, H, W)
+        code.append(c)
+        mask.append(m)
+    code, mask = np.concatenate(code, 0), np.concatenate(mask, 0)
+    y = orc.cconv_ec(x, w, b, None, G, 6)                                    # [3B, 3G, H, W], net-major
+    idx, pidx = orc.code_contex(H, W)
+    P = H + W + G - 2
+    want = np.zeros((B, G * H * W, 2), np.uint32)
+    plane_start = np.zeros(P + 1, np.int32)
+    k = 0
+    z, lab, mk = np.zeros(3 * 3 * H * W, np.float32), np.zeros(H * W, np.float32), np.zeros(H * W, np.float32)
+    for p in range(P):
+        plane_start[p] = k
+        tn = 0
+        for bi in range(B):
+            yb = np.ascontiguousarray(y[bi::B])                              # the three nets of image bi
+            tn = orc.tile_extract_batch(yb, z, G, idx, pidx, p)
+            tab = orc.gmm_table_batch(z, 3 * H * W, tn).astype(np.int64)
+            orc.tile_extract(code[bi:bi + 1], lab, G, True, idx, pidx, p)
+            orc.tile_extract(mask[bi:bi + 1], mk, G, True, idx, pidx, p)
+            s = lab[:tn].astype(np.int64)
+            keep = mk[:tn] >= 0.5
+            want[bi, k:k + tn, 0] = np.where(keep, tab[np.arange(tn), s], 0)
+            want[bi, k:k + tn, 1] = np.where(keep, tab[np.arange(tn), s + 1], 0)
+        k += tn
+    plane_start[P] = k
+    assert k == G * H * W
+    L = lic._lib
+    hp, wp = C.c_int(), C.c_int()
+    assert L.lic360_ec16_layout(H, W, C.byref(hp), C.byref(wp)) == 0
+    pad = lambda t: np.pad(t, ((0, 0), (0, 0), (2, hp.value - H - 2), (2, wp.value - W - 2)))
+    plan = C.c_void_p(0)
+    assert L.lic360_conv_plan_create(Cc, G, nout, 5, 6, C.byref(plan)) == 0
+    packed = torch.empty(3 * L.lic360_conv16_packed_floats(plan), dtype=torch.float32, device="cuda:0")
+    xd, wd, bd, cd, md = dev(pad(x)), dev(w), dev(b), dev(code), dev(mask)
+    pd, psd = dev(pidx.astype(np.int32)), dev(plane_start)
+    rec = torch.full((B, G * H * W, 2), -1, dtype=torch.int32, device="cuda:0")
+    ctr = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    s, Pp = lic._stream(0), lic._p
+    assert L.lic360_conv16_pack(s, plan, Pp(wd), 3, Pp(packed)) == 0
+    assert L.lic360_cconv16_ec_tables(s, plan, Pp(xd), Pp(packed), Pp(bd), Pp(cd), Pp(md), Pp(pd), Pp(psd), Pp(rec), B, H, W, Pp(ctr)) == 0, L.lic360_last_error()
+    got = host(rec).astype(np.int64).astype(np.uint32)
+    L.lic360_conv_plan_destroy(plan)
+    assert np.array_equal(got, want)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the rocprofv3 evidence behind profiles/rNN_* -- kernel stats of the default bench,
+# kernel stats of the encode / decode probes alone on the GPU, and the FETCH_SIZE / WRITE_SIZE passes (each counter in its own run).
+# usage: tools/collect_profiles.sh r02      -> gpurun_out/prof_r02/...
+set -e
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/bench -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
+echo bench done
+export PB=48
+rocprofv3 --kernel-trace --stats -d $O/dc -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_probe.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $O/ec -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_probe.txt 2>&1
+echo probes done
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C -d $O/dc_$C -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_$C.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $O/ec_$C -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_$C.txt 2>&1
+done
+echo pmc done
+cd $R
+python3 tools/pmc_traffic.py $O/pmc_traffic.json 48 $O/dc_FETCH_SIZE/p_counter_collection.csv $O/dc_WRITE_SIZE/p_counter_collection.csv \
+    $O/ec_FETCH_SIZE/p_counter_collection.csv $O/ec_WRITE_SIZE/p_counter_collection.csv
+python3 tools/stream_ops_bench.py > $O/stream_ops.json

@@ -1,28 +1,41 @@
-"""Build profiles/rNN_pmc_traffic.json from two rocprofv3 counter_collection.csv files (one --pmc FETCH_SIZE pass and one
---pmc WRITE_SIZE pass of `PB=32 python tools/dc_probe.py`, MI355X_MICROARCH.md HBM section: separate passes; both counters
-are in KB; on gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane streaming reads, so it is doubled)."""
-import csv, json, sys, collections
+"""Build profiles/rNN_pmc_traffic.json from rocprofv3 counter_collection.csv files: for each probe (tools/dc_probe.py, tools/ec_probe.py,
+PB images, single stream) one --pmc FETCH_SIZE pass and one --pmc WRITE_SIZE pass (MI355X_MICROARCH.md HBM section: separate passes;
+both counters are in KB and count the L2's memory-side requests, Infinity-Cache hits included; on gfx950 FETCH_SIZE reports half of
+the bytes of 16-B-per-lane streaming reads, so it is doubled).  Keys are bench.py's kernel classes.
 
-fetch_csv, write_csv, out_json, images = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+usage: pmc_traffic.py out.json images  dc_fetch.csv dc_write.csv  ec_fetch.csv ec_write.csv"""
+import collections
+import csv
+import json
+import sys
+
+CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16<4, false>", "ec_hidden"),
+           ("k_cconv16<4, true>", "ec_last"), ("k_cconv16<1, false>", "ec_first")]
+out_json, images = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
-for path, ctr in ((fetch_csv, "FETCH_SIZE"), (write_csv, "WRITE_SIZE")):
-    tot, disp = collections.defaultdict(float), collections.defaultdict(set)
+for path in sys.argv[3:]:
+    tot, disp, ctr = collections.defaultdict(float), collections.defaultdict(set), None
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != ctr:
+        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        ctr = r["Counter_Name"]
+        k = r["Kernel_Name"].replace("void ", "")
         tot[k] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     for k in tot:
-        res[k][ctr] = {"launches": len(disp[k]), "sum_KB": tot[k], "per_launch_KB": tot[k] / len(disp[k])}
-dom = [k for k in res if k.startswith("k_cconv4v6<4, false")][0]          # decode order, hidden layers
-rd = 2.0 * res[dom]["FETCH_SIZE"]["per_launch_KB"] * 1024
-wr = res[dom]["WRITE_SIZE"]["per_launch_KB"] * 1024
-json.dump({"command": "PB=%d rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/dc_probe.py  (one encode + one decode of %d images, "
-                      "single stream; separate passes per counter)" % (images, images),
-           "note": "FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane streaming reads "
-                   "(MI355X_MICROARCH.md, HBM section) -> doubled for hbm_read_bytes",
-           "kernels": res,
-           "dominant_kernel": {"name": dom, "images_per_launch": images, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
-                               "traffic_bytes_per_launch": rd + wr}}, open(out_json, "w"), indent=1)
-print(dom, "read %.1f MB + write %.1f MB per launch" % (rd / 1e6, wr / 1e6))
+        for pat, cls in CLASSES:
+            if k.startswith(pat):
+                res[cls][ctr] = {"kernel": k.split("(")[0], "launches": len(disp[k]), "per_launch_KB": tot[k] / len(disp[k])}
+doc = {"command": "PB=%d rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/{dc,ec}_probe.py (one encode + decodes of %d images, "
+                  "single stream; separate passes per counter)" % (images, images),
+       "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); Infinity-Cache hits are included in both counters; "
+               "dc_hidden averages the 10 hidden and the 1 last (cout = 3) launch of a plane, which run the same kernel"}
+for cls, d in res.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        rd, wr = 2.0 * d["FETCH_SIZE"]["per_launch_KB"] * 1024, d["WRITE_SIZE"]["per_launch_KB"] * 1024
+        doc[cls] = {"kernel": d["FETCH_SIZE"]["kernel"], "images_per_launch": images, "launches_profiled": d["FETCH_SIZE"]["launches"],
+                    "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
+json.dump(doc, open(out_json, "w"), indent=1)
+for cls in doc:
+    if isinstance(doc[cls], dict):
+        print(cls, "read %.1f MB + write %.1f MB per launch" % (doc[cls]["hbm_read_bytes_per_launch"] / 1e6, doc[cls]["hbm_write_bytes_per_launch"] / 1e6))
