@@ -252,6 +252,20 @@ LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, c
     return lic360_cconv4_dc_plane_mode(stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, mode);
 }
 
+// Floats to allocate for `planes` activation planes (samples x channels) of one of this file's padded layouts: the planes plus
+// the slack the band fetches of the last plane may touch (they are whole 16-byte quads of 11-row bands and are not clamped at
+// the end of the tensor).  Callers size and zero buffers with this instead of knowing the slack.
+//   layout: 0 = decode order (lic360_dc4_layout), 1 = encode order NCHW (lic360_ec4_layout), 2 = encode order wrapped diagonals
+//   (lic360_ec6_layout)
+#define C4_TAIL_FLOATS 4096
+LIC360_API long lic360_conv4_buffer_floats(int layout, long planes, int h, int w) {
+    if (planes <= 0 || h <= 0 || w <= 0) return 0;
+    long per = 0;
+    if (layout == 0) per = (long)D3_SP(h, w) * D3_HP(h);
+    else if (layout == 1) per = (long)E3_HP(h) * E3_WP(w);
+    else if (layout == 2 && w >= 7) per = (long)E6_ROWS(w) * D3_HP(h);
+    return per ? planes * per + C4_TAIL_FLOATS : 0;
+}
 LIC360_API int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0) {
     ARG_CHECK(rows && pitch && row0 && col0 && h > 0 && w > 0);
     *rows = D3_SP(h, w); *pitch = D3_HP(h); *row0 = D3_S0; *col0 = D3_C0;

@@ -353,7 +353,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     HIP_TRY(hipMemcpy(c->d_plane_start, c->h_plane_start.data(), c->h_plane_start.size() * 4, hipMemcpyHostToDevice));
     if (c->use4) { if (lic360_dc4_layout(h, w, &c->sk_rows, &c->sk_pitch, &c->sk_row0, &c->sk_col0)) return 1; }
     else { c->sk_rows = c->S; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
-    const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = 4096;   // TAIL: band fetches may run past the last row
+    const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = (size_t)lic360_conv4_buffer_floats(0, 1, h, w) - (size_t)c->sk_rows * c->sk_pitch;   // slack for the band fetches of the last plane
     // encode-order kernel (environment read once, here): default = 16x16x4 MFMA on zero-haloed NCHW planes; LIC360_EC=6 the
     // 4x4x1 kernel on wrapped diagonal-major planes, LIC360_EC4=3 (or LIC360_EC=3) the row-major LDS-DMA kernel (A/B runs)
     const char *force_ec4 = getenv("LIC360_EC4"), *force_ec = getenv("LIC360_EC");

@@ -303,6 +303,7 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
         c.profile(False)
 
     rows = []
+    iso_live = {k for k, (ms, n) in iso.items() if n}
     for cls, (ms, n) in iso.items():
         if n == 0:
             continue
@@ -324,12 +325,25 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
         rows.append(row)
     convs = [r for r in rows if r["bound"] == "mfma"]
     dom = max(convs, key=lambda r: r["total_ms"])
-    traffic = None
-    try:      # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, profiles/)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))[dom["kernel"]]
-        traffic = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
+    # fabric-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh;
+    # Infinity-Cache hits are counted), scaled to this run's images per launch
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
     except Exception:                                              # noqa: BLE001
-        traffic = None
+        pmc = {}
+    for r in rows:
+        pm = pmc.get(r["kernel"])
+        if isinstance(pm, dict):
+            r["traffic"] = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
+        if r["kernel"] == "ec_last" and "enc_tables" not in iso_live:
+            # the fused last layer + CDF-table kernel (N1): HBM view next to the MFMA view.  Algorithmic bytes: 3 nets x 4 channels in,
+            # symbol + mask in, one (cdf[sym], cdf[sym+1]) record out = 64 B per symbol, + the layer's weights once per launch
+            # (SURVEY.md 8d prices the unfused form, which writes the whole 9-entry row, at 113 B per symbol)
+            by = 64.0 * NSYM * b0 + 8.29e6
+            r["fused_with"] = "softmax / sigma floor / erf CDF / fix-up / (cdf[sym], cdf[sym+1]) record write (no y round trip, no enc_tables launch)"
+            r["hbm_view"] = {"algorithmic_bytes_per_launch": by, "bytes_per_symbol": by / (NSYM * b0), "achieved": by / (r["avg_launch_ms"] * 1e-3) / 1e9,
+                             "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": by / (r["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    traffic = dom.get("traffic")
     conv_ms = sum(r["total_ms"] for r in convs)
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["frac"], "traffic": traffic, "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],

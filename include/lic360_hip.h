@@ -131,10 +131,14 @@ int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *plan, const f
 /* Leaf-resident variant (v_mfma_f32_4x4x1, csrc/cconv4_kernels.hip) for the latent-net shapes cin in {1,4},
  * cout <= 4, ngroup <= 64: same results bit for bit, own weight layout.  EC: NCHW.  DC: zero-padded diagonal-major
  * activations [n][c][rows][pitch] with cell (s = th+tw, th) at [(s + row0) * pitch + th + col0] (lic360_dc4_layout; the
- * padding must be zero and the buffer must extend 16 KB past the last row), min(h,w) <= 64. */
+ * padding must be zero), min(h,w) <= 64.
+ * Buffers of the three lic360_conv4 layouts are sized with lic360_conv4_buffer_floats(layout, planes, h, w) -- layout 0 = dc4,
+ * 1 = ec4, 2 = ec6; planes = samples x channels -- which includes the slack the 16-byte band fetches of the last plane may touch
+ * (whole quads of 11-row bands, not clamped at the end of the tensor); the whole buffer starts zeroed. */
+long lic360_conv4_buffer_floats(int layout, long planes, int h, int w);
 int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0);
 /* encode order on zero-padded NCHW planes [hp][wp] with cell (r, c) at [(r+2)*wp + c+2] (lic360_ec4_layout): unconditional
- * 16-byte LDS-DMA tile fetches, persistent workgroups; the padding must be zero, buffers extend 16 KB past the end */
+ * 16-byte LDS-DMA tile fetches, persistent workgroups; the padding must be zero, buffers sized by lic360_conv4_buffer_floats(1, ...) */
 int lic360_ec4_layout(int h, int w, int *hp, int *wp);
 int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
                             const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);

@@ -382,12 +382,13 @@ def test_cconv4_ec_diag_bit_exact(lic, case):
     L.lic360_conv4_packed_floats.restype = C.c_long
     L.lic360_conv4_packed_floats.argtypes = [C.c_void_p]
     packed = torch.empty(nb * L.lic360_conv4_packed_floats(plan), dtype=torch.float32, device="cuda:0")
-    tail = torch.zeros(4096, dtype=torch.float32, device="cuda:0")                     # band fetches may run past the last row
+    total = L.lic360_conv4_buffer_floats(2, N * nout, H, W)                            # planes + the slack band fetches may touch
+    tail = torch.zeros(total - N * nout * maps[0] * maps[1], dtype=torch.float32, device="cuda:0")
     xd = torch.cat([dev(_to_ec6(x, maps)).flatten(), tail])
     rd = torch.cat([dev(_to_ec6(res, maps)).flatten(), tail])
     wd, bd = dev(w), dev(b)
     ad = dev(a) if act else None
-    out = torch.zeros(N * nout * maps[0] * maps[1] + 4096, dtype=torch.float32, device="cuda:0")
+    out = torch.zeros(total, dtype=torch.float32, device="cuda:0")
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     assert L.lic360_conv4_pack(s, plan, P(wd), nb, P(packed)) == 0
