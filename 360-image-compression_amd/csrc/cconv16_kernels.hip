@@ -135,6 +135,7 @@ struct C16Args {
     int *ctr;                                  // 8 task counters (one per XCD), zeroed by the host before the launch
     int G, cout, hidden, H, W, hp, wp, npb, x_mod, N;
     int n_gb, ntx, ntiles, n_chunks, NS;
+    int gbk;                                   // task order: blocks of gbk (sample, chunk) units, group block slowest inside a block
     // FUSE (last layer of the latent net + CDF-table build, SURVEY.md §7 k_cconv_ec_last_gmm): N = images, the three stacked
     // nets [weight, sigma, mu] of an image are swept one after the other inside a task
     const float *code, *mask;                  // [N, G, H, W] symbols / importance mask
@@ -211,8 +212,10 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]); };
     // task u -> sample n, first tile, group block (group block fastest: the workgroups of an XCD share the input region)
     auto decode = [&](int u, int &n, int &tile0, int &gb) __attribute__((always_inline)) {
-        gb = a.n_gb - 1 - u % a.n_gb;
-        const int v = u / a.n_gb;
+        const int units = ns_x * a.n_chunks, per = a.gbk * a.n_gb, blk = u / per, r = u - blk * per;
+        const int left = units - blk * a.gbk, kk = left < a.gbk ? left : a.gbk;
+        gb = a.n_gb - 1 - r / kk;
+        const int v = blk * a.gbk + r % kk;
         tile0 = (v % a.n_chunks) * C16_TPT;
         n = xcd + 8 * (v / a.n_chunks);
     };
@@ -535,6 +538,7 @@ static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w) {
     a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
     a.n_chunks = (a.ntiles + C16_TPT - 1) / C16_TPT;
     a.NS = conv16_nsteps_max(p);
+    { static const int k = getenv("LIC360_C16_K") ? atoi(getenv("LIC360_C16_K")) : 16; a.gbk = k > 0 ? k : 1; }
     a.code = a.mask = nullptr; a.pidx = a.plane_start = nullptr; a.rec = nullptr;
     return 0;
 }

@@ -131,29 +131,103 @@ __global__ void k_enc_tables(const float *__restrict__ y, const float *__restric
     }
 }
 
-// one wave per image; coder state is wave-uniform, lane 0 stores the bytes
+// Wave-resident bit sink of the encoder: pending bits collect in a 64-bit scalar; every full 32-bit word goes (big-endian) into
+// lane `wpos` of ONE VGPR (one v_cndmask), and the 256-byte window is stored with one coalesced dword store per 64 words --
+// no byte stores and no divergent code on the serial chain.  Words past the stream's slot are dropped, `len` keeps counting
+// (overflow is reported as error bit 16).  Streams start 4-byte aligned (cap % 4 == 0).
+struct DevBitSink {
+    uint8_t *buf;
+    long cap, wbase;            // wbase: byte offset of the window
+    unsigned long long acc;     // pending bits, right-aligned
+    int nacc, wpos, lane;       // nacc < 32 between puts; wpos: words in the window
+    uint32_t win;
+    __device__ __forceinline__ void init(uint8_t *b, long c, int l) { buf = b; cap = c; wbase = 0; acc = 0; nacc = 0; wpos = 0; lane = l; win = 0; }
+    __device__ __forceinline__ void flush() {
+        if (lane < wpos && wbase + 4 * lane + 4 <= cap) *(uint32_t *)(buf + wbase + 4 * lane) = win;
+        wbase += 4 * wpos;
+        wpos = 0;
+    }
+    __device__ __forceinline__ void put(uint32_t v, int n) {              // the low n bits of v (n <= 32), MSB first
+        acc = (acc << n) | (unsigned long long)(n == 32 ? v : (v & ((1u << n) - 1u)));
+        nacc += n;
+        if (nacc >= 32) {
+            nacc -= 32;
+            const uint32_t word = __builtin_bswap32((uint32_t)(acc >> nacc));
+            win = lane == wpos ? word : win;
+            if (++wpos == 64) flush();
+        }
+    }
+    __device__ __forceinline__ void put_run(int bit, unsigned long long n) {
+        const uint32_t pat = bit ? 0xffffffffu : 0u;
+        while (n >= 32) { put(pat, 32); n -= 32; }
+        if (n) put(pat, (int)n);
+    }
+    // zero-pad to a byte boundary, store what is left; returns the stream length in bytes
+    __device__ __forceinline__ long finish() {
+        const int tail = (nacc + 7) >> 3;                                 // bytes of the last, partial word
+        if (tail) {
+            const uint32_t word = __builtin_bswap32((uint32_t)(acc << (32 - nacc)));
+            win = lane == wpos ? word : win;
+        }
+        const long len = wbase + 4 * wpos + tail;
+        if (lane < wpos && wbase + 4 * lane + 4 <= cap) *(uint32_t *)(buf + wbase + 4 * lane) = win;
+        if (lane == wpos && tail) {
+            for (int i = 0; i < tail; ++i)
+                if (wbase + 4 * lane + i < cap) buf[wbase + 4 * lane + i] = (uint8_t)(win >> (8 * i));
+        }
+        return len;
+    }
+};
+// ArithmeticEncoder::write / shift / underflow (ArithmeticCoder.cpp:34-69) on the closed forms of ac_narrow
+__device__ __forceinline__ void ac_encode_symbol_dev(AcState &s, DevBitSink &w, uint32_t symLow, uint32_t symHigh) {
+    int n1, n2;
+    uint32_t lowb;
+    ac_narrow(s, symLow, symHigh, 65536u, n1, n2, lowb);
+    if (n1) {
+        if (s.underflow == 0) w.put(lowb >> (32 - n1), n1);               // the common case: the n1 leading bits of low in one put
+        else {
+            const int bit = (int)(lowb >> 31);
+            w.put((uint32_t)bit, 1);
+            w.put_run(bit ^ 1, s.underflow);
+            s.underflow = 0;
+            if (n1 > 1) w.put(lowb >> (32 - n1), n1 - 1);                 // bits 30 .. 32-n1 of low
+        }
+    }
+    s.underflow += (uint64_t)n2;
+}
+
+// one wave per image; coder state is wave-uniform (scalar registers)
 __global__ __launch_bounds__(64) void k_ac_encode(const uint2 *__restrict__ rec, long n, uint8_t *__restrict__ bytes, long cap,
                                                   int *__restrict__ nbytes, int *__restrict__ err) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const uint2 *r = rec + (long)b * n;
     AcState st;
     ac_init(st);
-    AcBitWriter bw;
-    ac_bw_init(bw, bytes + (long)b * cap, cap);
-    for (long base = 0; base < n; base += 64) {
+    DevBitSink bw;
+    bw.init(bytes + (long)b * cap, cap, lane);
+    // records are fetched two groups of 64 ahead of the serial chain
+    auto load_rec = [&](long base) __attribute__((always_inline)) {
         uint2 v = make_uint2(0u, 0u);
         if (base + lane < n) v = r[base + lane];
-        int cnt = (n - base) < 64 ? (int)(n - base) : 64;
-        for (int j = 0; j < cnt; ++j) {
-            uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.x, j);
-            uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)v.y, j);
-            if (hi != 0u) ac_encode_symbol(st, bw, lo, hi, 65536u);
+        return v;
+    };
+    uint2 v = load_rec(0), v1 = load_rec(64);
+    for (long base = 0; base < n; base += 64) {
+        const uint2 v2 = load_rec(base + 128);
+        unsigned long long todo = __ballot(v.y != 0u);                    // hi == 0: not coded (mask < 0.5, coder.cpp:79)
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.x, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)v.y, j);
+            ac_encode_symbol_dev(st, bw, lo, hi);
         }
+        v = v1; v1 = v2;
     }
-    ac_encode_finish(st, bw);
+    bw.put(1u, 1);                                                        // ArithmeticEncoder::finish writes a single 1
+    const long len = bw.finish();
     if (lane == 0) {
-        nbytes[b] = (int)bw.len;
-        err[b] = st.error | (bw.len > cap ? 16 : 0);
+        nbytes[b] = (int)len;
+        err[b] = st.error | (len > cap ? 16 : 0);
     }
 }
 
@@ -211,6 +285,61 @@ struct DevBits {
     }
 };
 
+// 8-symbol tables travel as ONE uint4 per symbol: the 7 inner CDF entries (each <= 65535 because T[8] = 65536 and the entries
+// increase) as 16-bit halves in binary-search order, plus the "coded" flag:
+//   x = T[4] | coded << 16,  y = T[2] | T[6] << 16,  z = T[1] | T[3] << 16,  w = T[5] | T[7] << 16
+__device__ __forceinline__ uint4 dec_pack8(const int *T) {
+    return make_uint4((unsigned)T[4] | 0x10000u, (unsigned)T[2] | ((unsigned)T[6] << 16), (unsigned)T[1] | ((unsigned)T[3] << 16),
+                      (unsigned)T[5] | ((unsigned)T[7] << 16));
+}
+// One symbol of the serial decode chain, wave-uniform, without a division.  ArithmeticDecoder::read (ArithmeticCoder.cpp:82-116)
+// finds value = ((offset+1)*total - 1) / range and the symbol with T[sym] <= value < T[sym+1]; since
+//   value >= T[k]  <=>  (offset+1)*total > T[k]*range  <=>  offset >= floor(T[k]*range / total)
+// the symbol is the number of k in 1..7 whose interval start  floor(T[k]*range >> 16)  is <= offset -- three binary-search
+// probes, each one multiply -- and the probes that bracket it ARE the new low / high of ac_narrow.  range = high-low+1 can be
+// 2^32, so the product is formed as T*(range-1) + T.
+template <class R>
+__device__ __forceinline__ int ac_decode_symbol8(AcState &s, R &bits, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ww) {
+    const uint32_t r1 = s.high - s.low, offset = s.code - s.low;
+    if (s.low >= s.high || r1 < (1u << 30) + 1u) s.error = 2;
+    auto start = [&](uint32_t t) { return (uint32_t)(((uint64_t)t * r1 + t) >> 16); };
+    uint32_t lo = 0, him1 = r1;                                         // interval [lo, him1] relative to low
+    uint32_t b = start(wx & 0xffffu);
+    const bool c1 = offset >= b;
+    if (c1) lo = b; else him1 = b - 1;
+    b = start(c1 ? wy >> 16 : wy & 0xffffu);
+    const bool c2 = offset >= b;
+    if (c2) lo = b; else him1 = b - 1;
+    const uint32_t w3 = c1 ? ww : wz;
+    b = start(c2 ? w3 >> 16 : w3 & 0xffffu);
+    const bool c3 = offset >= b;
+    if (c3) lo = b; else him1 = b - 1;
+    uint32_t low = s.low + lo, high = s.low + him1;
+    // renormalisation: the closed forms of ac_narrow
+    int n1 = ac_clz32(low ^ high);
+    if (n1 >= 32) { n1 = 31; s.error = 2; }
+    const uint32_t code1_msb = (s.code << n1) & 0x80000000u;             // bit 31 after the shift run (survives the underflow run)
+    low <<= n1;
+    high = (high << n1) | ((1u << n1) - 1u);
+    int n2 = ac_clz32(~((low & ~high) << 1));
+    if (n2 > 30) n2 = 30;
+    low = (low << n2) & 0x7fffffffu;
+    high = ((high << n2) & 0x7fffffffu) | 0x80000000u | ((1u << n2) - 1u);
+    const int n = n1 + n2;
+    uint32_t code;
+    if (n <= 32) {                                                      // both runs' bits in one read
+        const uint32_t nb = bits.get(n);
+        code = code1_msb | (((n == 32 ? 0u : s.code << n) | nb) & 0x7fffffffu);
+        if (n2 == 0) code = (s.code << n1) | nb;
+    } else {
+        code = (s.code << n1) | bits.get(n1);
+        code = (code & 0x80000000u) | ((code << n2) & 0x7fffffffu) | bits.get(n2);
+    }
+    s.low = low; s.high = high; s.code = code;
+    if (code < low || code > high) s.error = 3;
+    return (c1 ? 4 : 0) + (c2 ? 2 : 0) + (c3 ? 1 : 0);
+}
+
 // Decode of one plane runs as two kernels:
 //  k_dec_tables -- one thread per (image, plane position): the 7 inner CDF entries of the symbol from the three nets' outputs,
 //                  7 x int32 + a "coded" flag as two uint4 (massively parallel, register-hungry, short);
@@ -229,7 +358,7 @@ __global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, 
     const int q = start + i;
     const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
     const long nchw = (((long)b * G + g) * H + th) * W + tw;
-    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
     if (!(mask[nchw] < 0.5f)) {                                      // coder.cpp:79
         float v[9];
 #pragma unroll
@@ -239,11 +368,9 @@ __global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, 
                 v[net * 3 + c] = y[((long)(net * B + b) * (3 * G) + g * 3 + c) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0];
         int T[9];
         gmm_cdf9(v, v + 3, v + 6, T);                                // 0 = T[0] < T[1] < ... < T[8] = 65536
-        r0 = make_uint4((unsigned)T[1], (unsigned)T[2], (unsigned)T[3], (unsigned)T[4]);
-        r1 = make_uint4((unsigned)T[5], (unsigned)T[6], (unsigned)T[7], 1u);
+        r = dec_pack8(T);
     }
-    tab[((long)b * tab_pitch + i) * 2] = r0;
-    tab[((long)b * tab_pitch + i) * 2 + 1] = r1;
+    tab[(long)b * tab_pitch + i] = r;
 }
 
 // LINEAR (test hook lic360_devcoder_decode): symbols go to code_out[b*G + start + i] instead of the latent layouts
@@ -262,41 +389,45 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
     DevBits rd;
     rd.buf = bytes + (long)b * cap; rd.len = dev_stream_len(nbytes[b], cap); rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
     rd.fetch_window();
+    // the tables and scan positions of the NEXT group of 64 symbols are fetched before the serial chain of the current one
+    // runs, so that no memory latency sits between groups
+    auto load_tab = [&](int base) __attribute__((always_inline)) {
+        uint4 t = make_uint4(0u, 0u, 0u, 0u);
+        if (base + lane < len) t = tab[(long)b * tab_pitch + base + lane];
+        return t;
+    };
+    auto load_pos = [&](int base, int &th, int &tw) __attribute__((always_inline)) {
+        th = tw = 0;
+        if constexpr (!LINEAR) { if (base + lane < len) { th = idx[start + base + lane]; tw = idx[start + base + lane + HW]; } }
+    };
+    uint4 tcur = load_tab(0);
+    int th_cur, tw_cur;
+    load_pos(0, th_cur, tw_cur);
     for (int base = 0; base < len; base += 64) {
-        const int cnt = (len - base) < 64 ? (len - base) : 64;
-        const bool live = lane < cnt;
-        uint4 ta = make_uint4(0u, 0u, 0u, 0u), tb = ta;
-        if (live) { ta = tab[((long)b * tab_pitch + base + lane) * 2]; tb = tab[((long)b * tab_pitch + base + lane) * 2 + 1]; }
-        const bool coded = tb.w != 0u;
-        const unsigned long long cmask = __ballot(coded);
+        const bool live = base + lane < len;
+        const uint4 tnext = load_tab(base + 64);
+        int th_next, tw_next;
+        load_pos(base + 64, th_next, tw_next);
+        const bool coded = (tcur.x >> 16) != 0u;
+        unsigned long long todo = __ballot(coded);
         int symv = 0;
-        for (int j = 0; j < cnt; ++j) {
-            if (!((cmask >> j) & 1ull)) continue;
-            uint32_t t[9];
-            t[0] = 0; t[8] = 65536u;
-            t[1] = (uint32_t)__builtin_amdgcn_readlane((int)ta.x, j); t[2] = (uint32_t)__builtin_amdgcn_readlane((int)ta.y, j);
-            t[3] = (uint32_t)__builtin_amdgcn_readlane((int)ta.z, j); t[4] = (uint32_t)__builtin_amdgcn_readlane((int)ta.w, j);
-            t[5] = (uint32_t)__builtin_amdgcn_readlane((int)tb.x, j); t[6] = (uint32_t)__builtin_amdgcn_readlane((int)tb.y, j);
-            t[7] = (uint32_t)__builtin_amdgcn_readlane((int)tb.z, j);
-            const uint32_t target = ac_decode_target(st, 65536u);
-            int sym = 0;
-#pragma unroll
-            for (int k = 1; k < 8; ++k) sym += (target >= t[k]) ? 1 : 0;
-            uint32_t lo = 0, hi = 65536;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (sym == k) { lo = t[k]; hi = t[k + 1]; }
-            ac_decode_consume_from(st, rd, lo, hi, 65536u);
+        while (todo) {                                                  // the coded symbols of this group of 64, in order
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)tcur.x, j), wy = (uint32_t)__builtin_amdgcn_readlane((int)tcur.y, j);
+            const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)tcur.z, j), ww = (uint32_t)__builtin_amdgcn_readlane((int)tcur.w, j);
+            const int sym = ac_decode_symbol8(st, rd, wx, wy, wz, ww);
             symv = (lane == j) ? sym : symv;
         }
         if (live) {
-            const int q = start + base + lane;
-            if constexpr (LINEAR) code_out[(long)b * G + q] = coded ? (float)symv : 0.0f;
+            if constexpr (LINEAR) code_out[(long)b * G + start + base + lane] = coded ? (float)symv : 0.0f;
             else {
-                const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
+                const int th = th_cur, tw = tw_cur, g = p - th - tw;
                 x0[((long)b * G + g) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0] = coded ? (float)symv - 3.5f : 0.0f;
                 code_out[(((long)b * G + g) * H + th) * W + tw] = coded ? (float)symv : 0.0f;
             }
         }
+        tcur = tnext; th_cur = th_next; tw_cur = tw_next;
     }
     if (lane == 0) {
         ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error |= st.error;     // sticky: coder faults 1..3, clamp flag 32
@@ -377,7 +508,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     rc |= dmalloc(&c->d_state, B);
     for (int p = 0; p < c->P; ++p) c->tab_pitch = std::max(c->tab_pitch, c->h_plane_start[p + 1] - c->h_plane_start[p]);
     c->tab_pitch = (c->tab_pitch + 63) / 64 * 64;
-    rc |= dmalloc(&c->d_tab, 2 * B * (size_t)c->tab_pitch);
+    rc |= dmalloc(&c->d_tab, B * (size_t)c->tab_pitch);
     if (rc) return 1;
     // decode activations are only ever read where already written or with a zero weight; they must be finite
     HIP_TRY(hipMemset(c->e_x0, 0, (B * G * EPL + TAIL) * 4));
@@ -822,13 +953,13 @@ __global__ void k_test_records(const int *__restrict__ tables, int ncode, const 
         rec[i] = r;
     }
 }
-__global__ void k_test_tab8(const int *__restrict__ tables, const float *__restrict__ mask, long start, int len, uint4 *__restrict__ tab) {
+__global__ void k_test_tab8(const int *__restrict__ tables, const float *__restrict__ mask, long start, int len, uint4 *__restrict__ tab, AcDevState *st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     const int *T = tables + (start + i) * 9;
     const bool coded = !mask || !(mask[start + i] < 0.5f);
-    tab[2 * i] = coded ? make_uint4(T[1], T[2], T[3], T[4]) : make_uint4(0u, 0u, 0u, 0u);
-    tab[2 * i + 1] = coded ? make_uint4(T[5], T[6], T[7], 1u) : make_uint4(0u, 0u, 0u, 0u);
+    if (coded && ((T[1] | T[2] | T[3] | T[4] | T[5] | T[6] | T[7]) & ~0xffff)) atomicOr(&st->error, 64);   // inner entries must fit 16 bits
+    tab[i] = coded ? dec_pack8(T) : make_uint4(0u, 0u, 0u, 0u);
 }
 __global__ void k_test_tabn(const int *__restrict__ tables, int ncode, long start, int len, int *__restrict__ tab) {
     const int i = blockIdx.x, k = threadIdx.x;
@@ -863,13 +994,13 @@ LIC360_API int lic360_devcoder_decode(void *stream, const int *tables, int ncode
     AcDevState *st = nullptr;
     uint4 *tab8 = nullptr;
     int *tabn = nullptr;
-    if (dmalloc(&st, 1) || dmalloc(&tab8, 2 * (size_t)chunk) || dmalloc(&tabn, (size_t)chunk * IMP_TW)) return 1;
+    if (dmalloc(&st, 1) || dmalloc(&tab8, (size_t)chunk) || dmalloc(&tabn, (size_t)chunk * IMP_TW)) return 1;
     hipLaunchKernelGGL(k_dec_init, dim3(1), dim3(64), 0, s, bytes, cap, nbytes, st, 1);
     LAUNCH_CHECK();
     for (long start = 0; start < n; start += chunk) {
         const int len = (int)std::min<long>(chunk, n - start);
         if (ncode == 8) {
-            hipLaunchKernelGGL(k_test_tab8, dim3((len + 63) / 64), dim3(64), 0, s, tables, mask, start, len, tab8);
+            hipLaunchKernelGGL(k_test_tab8, dim3((len + 63) / 64), dim3(64), 0, s, tables, mask, start, len, tab8, st);
             LAUNCH_CHECK();
             hipLaunchKernelGGL(k_dec_plane<true>, dim3(1), dim3(64), 0, s, tab8, chunk, (const int *)nullptr, (int)start, len, 0, st, bytes, cap, nbytes,
                                (float *)nullptr, out, 0, 1, 1, 0, 0, 0, 0);

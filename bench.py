@@ -314,7 +314,7 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
             row.update(bound="mfma", achieved=fl / (ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                        algorithmic_flops_per_launch=fl / n)
         elif cls in ("enc_tables", "dec_tables"):
-            per_sym = 52.0 if cls == "enc_tables" else 72.0        # 9 floats of net output + symbol/mask in; (lo,hi) record or 7 entries + flag out
+            per_sym = 52.0 if cls == "enc_tables" else 56.0        # 9 floats of net output + symbol/mask in; (lo,hi) record or 7 packed 16-bit entries + flag out
             by = per_sym * NSYM * b0
             row.update(bound="hbm", achieved=by / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", algorithmic_bytes_per_launch=by / n)
         else:                                                      # serial arithmetic-coder chains: one wave per image

@@ -243,7 +243,9 @@ int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *byte
  * (every table totals 65536), labels and an optional mask, all in device memory, through the same kernels the codec
  * launches -- encode: k_ac_encode; decode: k_dec_init + k_dec_plane (ncode == 8) or k_imp_dec_plane (other alphabets),
  * `chunk` symbols per launch with the coder state carried between launches like between planes.  Reference behaviour:
- * extension/coder.cpp:30-113 over extension/ArithmeticCoder.cpp:34-116.  Synchronises the stream before returning. */
+ * extension/coder.cpp:30-113 over extension/ArithmeticCoder.cpp:34-116.  Synchronises the stream before returning.
+ * The 8-symbol decoder carries the 7 inner table entries as 16-bit values (they are < 65536 whenever the last symbol has a
+ * non-zero frequency, as every table of this codec does); a table that does not fit sets error bit 64. */
 int lic360_devcoder_encode(void *stream, const int *tables, int ncode, const int *labels, const float *mask, long n,
                            uint8_t *bytes, long cap, int *nbytes, int *err);
 int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const float *mask, long n, int chunk,
