@@ -239,12 +239,14 @@ int lic360_cconv4_dc_plane_mode(void *stream, const lic360_conv_plan *p, const f
     ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
     if ((mode & 1) && (h <= 64 || w <= 64)) return launch_cconv4v3_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod);
-    return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, (mode & 2) != 0);
+    return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, (mode & 2) != 0,
+                              (mode >> 2) & 3);
 }
 // LIC360_DC4=3 / LIC360_NOPACK select the A/B variants; the environment is read once per process, not per launch
 int lic360_dc4_env_mode(void) {
     const char *v = getenv("LIC360_DC4");
-    return ((v && v[0] == '3') ? 1 : 0) | (getenv("LIC360_NOPACK") ? 2 : 0);
+    const char *gsm = getenv("LIC360_DC_GSTEP");                     // "1": one group per task always, "3": never (default: by task count)
+    return ((v && v[0] == '3') ? 1 : 0) | (getenv("LIC360_NOPACK") ? 2 : 0) | (gsm && gsm[0] == '1' ? 4 : (gsm && gsm[0] == '3' ? 8 : 0));
 }
 LIC360_API int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {

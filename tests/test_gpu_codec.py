@@ -131,6 +131,24 @@ def test_fused_codec_previous_generation_kernels(monkeypatch, G, H, W, B, seed):
             monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("gstep", ["1", "3"])
+@pytest.mark.parametrize("G,H,W,B,seed", [(6, 8, 12, 3, 41), (48, 8, 16, 2, 42), (7, 64, 12, 1, 43), (4, 66, 10, 1, 44)])
+def test_fused_codec_decode_task_granularity(monkeypatch, gstep, G, H, W, B, seed):
+    """decode-order conv tasks of three groups (throughput) or of one group (latency mode, picked automatically for few samples):
+    LIC360_DC_GSTEP forces either; both decode the oracle's bitstreams exactly"""
+    from lic360_fused import FusedCodec
+    rng = np.random.default_rng(seed)
+    layers = rc.make_main_params(2000 + seed, G)
+    items = [latent(rng, G, H, W) for _ in range(B)]
+    code = np.concatenate([it[0] for it in items], 0)
+    mask = np.concatenate([it[1] for it in items], 0)
+    ref = [rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G) for i in range(B)]
+    monkeypatch.setenv("LIC360_DC_GSTEP", gstep)
+    fc = FusedCodec(G, H, W, max_batch=B)
+    fc.load_layers(layers)
+    assert np.array_equal(fc.decode(ref, dev(mask)).cpu().numpy(), code * mask)
+
+
 @pytest.mark.parametrize("cpg,nsym,H,W,B,seed", [(8, 49, 8, 12, 3, 31), (144, 49, 4, 6, 1, 32), (16, 10, 32, 10, 2, 33)])
 def test_fused_importance_codec_matches_oracle(cpg, nsym, H, W, B, seed):
     """Device-resident importance-map stream: byte-identical to the oracle's ImpEntEncoderFast pipeline, exact decode."""
