@@ -254,27 +254,27 @@ __global__ void k_dec_init(const uint8_t *__restrict__ bytes, long cap, const in
 // the 256-byte window is re-fetched with one coalesced load when the read position leaves it.
 struct DevBits {
     const uint8_t *buf;
-    long len, pos;              // pos: next unread byte (multiple of 4)
+    int len, pos;               // pos: next unread byte (multiple of 4); streams are < 2 GB
     unsigned long long acc;
     int nacc;
-    long wbase;
+    int wbase;
     uint32_t win;
     int lane;
     __device__ __forceinline__ void fetch_window() {
         wbase = pos;
-        const long o = wbase + 4 * lane;
+        const int o = wbase + 4 * lane;
         uint32_t w = 0;
         if (o < len) {
             w = *(const uint32_t *)(buf + o);                           // streams start 4-byte aligned (cap % 4 == 0)
             w = __builtin_bswap32(w);
-            if (o + 4 > len) w &= 0xffffffffu << (8 * (int)(o + 4 - len));
+            if (o + 4 > len) w &= 0xffffffffu << (8 * (o + 4 - len));
         }
         win = w;
     }
     __device__ __forceinline__ uint32_t get(int n) {
         if (nacc < n) {
             if (pos >= wbase + 256) fetch_window();
-            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)((pos - wbase) >> 2));
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, (pos - wbase) >> 2);
             acc = (acc << 32) | w;
             nacc += 32;
             pos += 4;
@@ -298,26 +298,31 @@ __device__ __forceinline__ uint4 dec_pack8(const int *T) {
 // the symbol is the number of k in 1..7 whose interval start  floor(T[k]*range >> 16)  is <= offset -- three binary-search
 // probes, each one multiply -- and the probes that bracket it ARE the new low / high of ac_narrow.  range = high-low+1 can be
 // 2^32, so the product is formed as T*(range-1) + T.
+// The reference's range / consistency assertions (errors 2 and 3 of ac_core.h) cannot fire inside this function: the symbol is
+// chosen so that low+lo <= code <= low+him1, and the renormalisation maps that interval and the code by the same shifts.  They
+// are checked once per launch on the state that enters and leaves (ac_state_check) instead of per symbol.
 template <class R>
 __device__ __forceinline__ int ac_decode_symbol8(AcState &s, R &bits, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ww) {
     const uint32_t r1 = s.high - s.low, offset = s.code - s.low;
-    if (s.low >= s.high || r1 < (1u << 30) + 1u) s.error = 2;
     auto start = [&](uint32_t t) { return (uint32_t)(((uint64_t)t * r1 + t) >> 16); };
     uint32_t lo = 0, him1 = r1;                                         // interval [lo, him1] relative to low
     uint32_t b = start(wx & 0xffffu);
     const bool c1 = offset >= b;
+    int sym = c1 ? 4 : 0;
     if (c1) lo = b; else him1 = b - 1;
     b = start(c1 ? wy >> 16 : wy & 0xffffu);
     const bool c2 = offset >= b;
+    sym |= c2 ? 2 : 0;
     if (c2) lo = b; else him1 = b - 1;
     const uint32_t w3 = c1 ? ww : wz;
     b = start(c2 ? w3 >> 16 : w3 & 0xffffu);
     const bool c3 = offset >= b;
+    sym |= c3 ? 1 : 0;
     if (c3) lo = b; else him1 = b - 1;
     uint32_t low = s.low + lo, high = s.low + him1;
     // renormalisation: the closed forms of ac_narrow
     int n1 = ac_clz32(low ^ high);
-    if (n1 >= 32) { n1 = 31; s.error = 2; }
+    if (n1 > 31) n1 = 31;                                               // low == high: flagged by ac_state_check at the end of the launch
     const uint32_t code1_msb = (s.code << n1) & 0x80000000u;             // bit 31 after the shift run (survives the underflow run)
     low <<= n1;
     high = (high << n1) | ((1u << n1) - 1u);
@@ -336,8 +341,12 @@ __device__ __forceinline__ int ac_decode_symbol8(AcState &s, R &bits, uint32_t w
         code = (code & 0x80000000u) | ((code << n2) & 0x7fffffffu) | bits.get(n2);
     }
     s.low = low; s.high = high; s.code = code;
-    if (code < low || code > high) s.error = 3;
-    return (c1 ? 4 : 0) + (c2 ? 2 : 0) + (c3 ? 1 : 0);
+    return sym;
+}
+__device__ __forceinline__ void ac_state_check(AcState &s) {
+    const uint32_t r1 = s.high - s.low;
+    if (s.low >= s.high || r1 < (1u << 30) + 1u) s.error = 2;
+    if (s.code < s.low || s.code > s.high) s.error = 3;
 }
 
 // Decode of one plane runs as two kernels:
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
         }
         tcur = tnext; th_cur = th_next; tw_cur = tw_next;
     }
+    ac_state_check(st);
     if (lane == 0) {
         ds.low = st.low; ds.high = st.high; ds.code = st.code; ds.error |= st.error;     // sticky: coder faults 1..3, clamp flag 32
         ds.pos = rd.pos; ds.acc = rd.acc; ds.nacc = rd.nacc;
@@ -610,7 +620,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
 LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
                                    const float *mask, int B, float *code_out, int *err) {
     if (check_ready(c, B)) return 2;
-    ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0 && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
+    ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
     const int G = c->G, H = c->H, W = c->W;
     hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
@@ -899,7 +909,7 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
 LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
                                       float *levels_out, int *err) {
     if (imp_ready(c, B)) return 2;
-    ARG_CHECK(bytes && nbytes && levels_out && err && cap > 0 && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
+    ARG_CHECK(bytes && nbytes && levels_out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
     const int H = c->H, W = c->W;
     hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
@@ -988,7 +998,7 @@ LIC360_API int lic360_devcoder_encode(void *stream, const int *tables, int ncode
 // uint4 + coded flag), any other alphabet (< 64) k_imp_dec_plane (one table entry per lane).  out[i] = symbol, 0 where masked.
 LIC360_API int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const float *mask, long n, int chunk,
                                       const uint8_t *bytes, long cap, const int *nbytes, float *out, int *err) {
-    ARG_CHECK(ncode >= 1 && ncode < IMP_TW && n >= 0 && chunk > 0 && bytes && nbytes && out && err && cap > 0 && cap % 4 == 0 &&
+    ARG_CHECK(ncode >= 1 && ncode < IMP_TW && n >= 0 && chunk > 0 && bytes && nbytes && out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 &&
               ((uintptr_t)bytes & 3) == 0 && (n == 0 || tables) && (ncode == 8 || !mask));
     hipStream_t s = (hipStream_t)stream;
     AcDevState *st = nullptr;
