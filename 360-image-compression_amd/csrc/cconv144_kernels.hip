@@ -122,6 +122,7 @@ struct I144Args {
     int opitch, ooff;                           //   cell (r, c) at [(r + ooff) * opitch + c + ooff] (EC)
     int tiles_r, tiles_c;                       // EC: row blocks / column blocks per map
     int s, th_lo, th_hi, th0;                   // DC: anti-diagonal, its valid rows, first row of the task's window (multiple of 4: 16-byte DMAs)
+    int n_seg;                                  // DC: 16 NT-row segments of the anti-diagonal (maps taller than one task's window)
     int og, n_og;                               // DC: output-channel tiles per task / tasks per map (a plane of one map is little work:
                                                 //     several workgroups share it, each staging the map's x tile for its own tiles)
 };
@@ -155,15 +156,18 @@ __device__ __forceinline__ void i144_body(const I144Args &a, float *xs, float *c
         soff[m] = (int)(pl * a.xplane) + row * a.xpitch + cq * 4;
     }
     const int kq = lane >> 4, j = lane & 15;
-    const int ntasks = DC ? a.N * a.n_og : a.N * a.tiles_r * a.tiles_c;
+    const int ntasks = DC ? a.N * a.n_og * a.n_seg : a.N * a.tiles_r * a.tiles_c;
     int parity = 0;
     for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
         // ---- task geometry
-        int n, r0 = 0, c0 = 0, ot_lo = 0, ot_hi = a.n_ot;
+        int n, r0 = 0, c0 = 0, ot_lo = 0, ot_hi = a.n_ot, th0 = 0;
         if constexpr (DC) {
-            n = task / a.n_og;
-            ot_lo = (task - n * a.n_og) * a.og;
+            const int per = a.n_og * a.n_seg;
+            n = task / per;
+            const int rem = task - n * per, seg = rem / a.n_og;
+            ot_lo = (rem - seg * a.n_og) * a.og;
             ot_hi = ot_lo + a.og < a.n_ot ? ot_lo + a.og : a.n_ot;
+            th0 = a.th0 + seg * (16 * NT);
         } else {
             n = task / (a.tiles_r * a.tiles_c);
             const int rem = task - n * (a.tiles_r * a.tiles_c);
@@ -171,7 +175,7 @@ __device__ __forceinline__ void i144_body(const I144Args &a, float *xs, float *c
             c0 = (rem % a.tiles_c) * 16;
         }
         // tile origin in the input plane: EC padded (r0, c0) [= image (r0-2, c0-2)]; DC row s - 4 + R0, column th0 (= image row th0 - 2)
-        const float *xt = a.x + (long)n * a.xsample + (DC ? (long)(a.s - 4 + I144_R0) * a.xpitch + a.th0 : (long)r0 * a.xpitch + c0);
+        const float *xt = a.x + (long)n * a.xsample + (DC ? (long)(a.s - 4 + I144_R0) * a.xpitch + th0 : (long)r0 * a.xpitch + c0);
         __syncthreads();                                                    // every wave is done with the previous x tile
         static_for<NDMA>([&](auto mm) {
             constexpr int m = decltype(mm)::value;
@@ -244,7 +248,7 @@ __device__ __forceinline__ void i144_body(const I144Args &a, float *xs, float *c
                 bool ok = o < a.nout;
                 long oi;
                 if constexpr (DC) {
-                    const int th = a.th0 + 16 * t + jj;
+                    const int th = th0 + 16 * t + jj;
                     ok = ok && th >= a.th_lo && th <= a.th_hi;
                     oi = (long)n * a.osample + (long)o * a.oplane + (long)(a.s + I144_R0) * a.opitch + th + I144_C0;
                 } else {
@@ -306,7 +310,7 @@ LIC360_API int lic360_cconv144_ec(void *stream, const lic360_conv_plan *p, const
     a.xplane = (long)hp * wp; a.xsample = 144 * a.xplane; a.xpitch = wp;
     a.oplane = oplane; a.osample = (long)p->nout * oplane; a.opitch = opitch; a.ooff = ooff;
     a.tiles_r = (h + I144_NT_EC - 1) / I144_NT_EC; a.tiles_c = (w + 15) / 16;
-    a.s = a.th_lo = a.th_hi = a.th0 = 0; a.og = a.n_ot; a.n_og = 1;
+    a.s = a.th_lo = a.th_hi = a.th0 = 0; a.og = a.n_ot; a.n_og = 1; a.n_seg = 1;
     const long ntasks = (long)n * a.tiles_r * a.tiles_c;
     const dim3 grid((unsigned)(ntasks < 256 ? ntasks : 256));
     hipLaunchKernelGGL((k_cconv144<1, false, I144_NT_EC>), grid, dim3(I144_THREADS), 0, (hipStream_t)stream, a);
@@ -315,7 +319,7 @@ LIC360_API int lic360_cconv144_ec(void *stream, const lic360_conv_plan *p, const
 }
 
 // Decode order, plane (= anti-diagonal) s of every map: x / out / residual are zero-padded diagonal-major planes
-// [n][c][h + w - 1 + 8][h + 4] (lic360_dc144_layout): cell (th, tw) at row th + tw + 4, column th + 2.  h <= 32.
+// [n][c][h + w - 1 + 8][h + 4] (lic360_dc144_layout): cell (th, tw) at row th + tw + 4, column th + 2.
 LIC360_API int lic360_dc144_layout(int h, int w, int *rows, int *pitch) {
     ARG_CHECK(rows && pitch && h > 0 && w > 0);
     *rows = h + w - 1 + 2 * I144_R0;
@@ -324,7 +328,7 @@ LIC360_API int lic360_dc144_layout(int h, int w, int *rows, int *pitch) {
 }
 LIC360_API int lic360_cconv144_dc_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed144, const float *bias,
                                         const float *act, const float *residual, float *out, int n, int h, int w, int s) {
-    ARG_CHECK(p && conv144_ok(p) && x && packed144 && bias && out && n > 0 && h > 0 && h <= 16 * I144_NT_DC && w > 0);
+    ARG_CHECK(p && conv144_ok(p) && x && packed144 && bias && out && n > 0 && h > 0 && w > 0);
     if (s < 0 || s >= h + w - 1) return 0;
     I144Args a;
     int rows, pitch;
@@ -336,10 +340,11 @@ LIC360_API int lic360_cconv144_dc_plane(void *stream, const lic360_conv_plan *p,
     a.tiles_r = a.tiles_c = 1;
     a.s = s; a.th_lo = s >= w ? s - w + 1 : 0; a.th_hi = s < h ? s : h - 1; a.th0 = a.th_lo & ~3;
     // split a map's output tiles over enough workgroups to occupy the chip (each re-stages the map's 104 KB x tile)
+    a.n_seg = (a.th_hi - a.th0) / (16 * I144_NT_DC) + 1;
     a.og = a.n_ot;
-    while (a.og > 1 && (long)n * ((a.n_ot + a.og - 1) / a.og) < 192) --a.og;
+    while (a.og > 1 && (long)n * a.n_seg * ((a.n_ot + a.og - 1) / a.og) < 192) --a.og;
     a.n_og = (a.n_ot + a.og - 1) / a.og;
-    const long ntasks = (long)n * a.n_og;
+    const long ntasks = (long)n * a.n_og * a.n_seg;
     const dim3 grid((unsigned)(ntasks < 256 ? ntasks : 256));
     hipLaunchKernelGGL((k_cconv144<1, true, I144_NT_DC>), grid, dim3(I144_THREADS), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();

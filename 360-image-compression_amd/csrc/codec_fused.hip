@@ -796,7 +796,7 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], B * CE * HW);
     rc |= dmalloc(&c->e_rec, B * HW);
     // 144-channel layers on the leaf-resident 16x16x4 kernels (LIC360_IMP144=0 keeps the generic kernels: A/B runs)
-    { const char *f = getenv("LIC360_IMP144"); c->use144 = lic360_conv144_supported(c->plan[1]) && lic360_conv144_supported(c->plan[2]) && h <= 32 && !(f && f[0] == '0'); }
+    { const char *f = getenv("LIC360_IMP144"); c->use144 = lic360_conv144_supported(c->plan[1]) && lic360_conv144_supported(c->plan[2]) && !(f && f[0] == '0'); }
     if (c->use144) {
         if (lic360_ec144_layout(h, w, &c->e_hp, &c->e_wp) || lic360_dc144_layout(h, w, &c->sk_rows, &c->sk_pitch)) return 1;
         c->sk_row0 = 4; c->sk_col0 = 2;

@@ -65,12 +65,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def synth_latents(batch, seed0):
+def synth_latents(batch, seed0, h=H, w=W):
     import numpy as np
     from util import latent
     codes, masks, levels = [], [], []
     for i in range(batch):
-        c, m, lv = latent(np.random.default_rng(seed0 + i), G, H, W)
+        c, m, lv = latent(np.random.default_rng(seed0 + i), G, h, w)
         codes.append(c)
         masks.append(m)
         levels.append(lv)
@@ -217,6 +217,41 @@ def run_rank(args):
         ok = ok and exact(cd4, mk4, lv4)
         extras["config4"] = {"images": 64, "images_per_gpu": len(mine), "ms": dt4 / 3 * 1e3, "value": 64 * PIXELS / (dt4 / 3) / 1e6, "unit": "Mpixel/s",
                              "scaling": "strong", "note": "BASELINE.json configs[3]: fixed list of 64 images, image i -> rank i mod N, both streams"}
+        # BASELINE.json configs[4]: LIC3602K 1024x2048 ERPs (48x128x256 latents, 32x64 -> 64x128 importance maps), model-idx 7 seed,
+        # 16 images per stream through codecs of their own (decode order runs on 64-row windows there, DESIGN.md 4.1 b)
+        try:
+            H5, W5, B5 = 2 * H, 2 * W, 16
+            l5, il5 = make_main_params(1000 * SSIM + 7, G), make_imp_params(1000 * SSIM + 7)
+            c5 = [FusedCodec(G, H5, W5, max_batch=B5, device=local) for _ in range(ns)]
+            i5 = [FusedImpCodec(H5 // 2, W5 // 2, max_batch=B5, device=local) for _ in range(ns)]
+            for c in c5:
+                c.load_layers(l5)
+            for c in i5:
+                c.load_layers(il5)
+            cd, mk, lv = synth_latents(B5 * ns, seed0=5000000 + 1000 * rank, h=H5, w=W5)
+            cd5 = [torch.from_numpy(cd[i * B5:(i + 1) * B5]).to(dev) for i in range(ns)]
+            mk5 = [torch.from_numpy(mk[i * B5:(i + 1) * B5]).to(dev) for i in range(ns)]
+            lv5 = [torch.from_numpy(lv[i * B5:(i + 1) * B5]).to(dev) for i in range(ns)]
+
+            def run5():
+                for ph in (0, 1):
+                    for c, ic, a, b_, l_, st, ist in zip(c5, i5, cd5, mk5, lv5, streams, istreams):
+                        with torch.cuda.stream(ist):
+                            ic.encode_async(l_) if ph == 0 else ic.decode_async(B5)
+                        with torch.cuda.stream(st):
+                            c.encode_async(a, b_) if ph == 0 else c.decode_async(b_, B5)
+            run5()
+            dt5 = shard.timed(run5, 2, dev)
+            ok5 = all(bool(torch.equal(c.code_out[:B5], a * b_)) and int(c.err[:B5].abs().sum().item()) == 0 for c, a, b_ in zip(c5, cd5, mk5))
+            ok5 = ok5 and all(bool(torch.equal(ic.levels_out[:B5], l_)) and int(ic.err[:B5].abs().sum().item()) == 0 for ic, l_ in zip(i5, lv5))
+            ok = ok and ok5
+            extras["config5"] = {"images_per_gpu": B5 * ns, "ms": dt5 / 2 * 1e3, "value": world * B5 * ns * 4 * PIXELS / (dt5 / 2) / 1e6, "unit": "Mpixel/s",
+                                 "roundtrip_exact": ok5, "mean_latent_bytes": float(np.mean([float(c.nbytes[:B5].float().mean().item()) for c in c5])),
+                                 "note": "BASELINE.json configs[4]: 1024x2048 ERPs (48x128x256 latents), model-idx 7 seed, both streams, %d images on %d streams" % (B5 * ns, ns)}
+            del c5, i5, cd5, mk5, lv5
+            torch.cuda.empty_cache()
+        except Exception as e:                                         # noqa: BLE001  (never lose the headline to a side figure)
+            extras["config5"] = {"error": repr(e)[:300]}
     ok = shard.all_ok(ok, dev)
 
     if rank == 0:

@@ -184,7 +184,7 @@ int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *plan, const f
  * v_mfma_f32_16x16x4_f32 (csrc/cconv144_kernels.hip): same results bit for bit as lic360_cconv_ec / lic360_cconv_dc_plane.
  * Encode order: x = zero-haloed NCHW planes [n][144][hp][wp] (lic360_ec144_layout, cell (r, c) at [(r+2)*wp + c+2]); out /
  * residual = [n][nout] planes with stride oplane, rows of opitch floats, cell (r, c) at [(r+ooff)*opitch + c+ooff] (ooff 2 =
- * the same haloed layout, 0 = plain NCHW).  Decode order (plane = anti-diagonal s of every map, h <= 32): x / residual / out are
+ * the same haloed layout, 0 = plain NCHW).  Decode order (plane = anti-diagonal s of every map): x / residual / out are
  * zero-padded diagonal-major planes [n][c][rows][pitch] (lic360_dc144_layout), cell (th, tw) at [(th+tw+4)*pitch + th+2]. */
 int lic360_conv144_supported(const lic360_conv_plan *plan);
 long lic360_conv144_packed_floats(const lic360_conv_plan *plan);

@@ -543,7 +543,8 @@ def test_cconv144_ec_bit_exact(lic, case):
     assert np.array_equal(got, want), "max abs diff %g" % np.abs(got - want).max()
 
 
-@pytest.mark.parametrize("case", [(2, 6, 9, 144, True), (1, 32, 64, 49, False), (3, 5, 3, 144, True), (2, 32, 7, 144, True)], ids=lambda c: "n%d_%dx%d_to%d" % c[:4])
+@pytest.mark.parametrize("case", [(2, 6, 9, 144, True), (1, 32, 64, 49, False), (3, 5, 3, 144, True), (2, 32, 7, 144, True),
+                                  (1, 64, 20, 144, True), (2, 45, 70, 49, False)], ids=lambda c: "n%d_%dx%d_to%d" % c[:4])   # the last two: diagonals longer than one task window
 def test_cconv144_dc_planes_bit_exact(lic, case):
     """decode order on the zero-padded diagonal-major layout: after every plane the persistent output equals the oracle's"""
     import ctypes as C

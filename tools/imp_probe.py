@@ -5,10 +5,11 @@ import torch, numpy as np
 import ref_codec as rc
 from lic360_fused import FusedImpCodec
 B = int(os.environ.get("PB", "32"))
+MH, MW = int(os.environ.get("MH", "32")), int(os.environ.get("MW", "64"))          # 64 x 128 = the maps of 1024x2048 ERPs
 layers = rc.make_imp_params(1003)
-fc = FusedImpCodec(32, 64, max_batch=B); fc.load_layers(layers)
+fc = FusedImpCodec(MH, MW, max_batch=B); fc.load_layers(layers)
 rng = np.random.default_rng(0)
-lv = torch.from_numpy(np.clip(np.rint(24 + 12 * rng.standard_normal((B, 1, 32, 64))), 0, 48).astype(np.float32)).cuda()
+lv = torch.from_numpy(np.clip(np.rint(24 + 12 * rng.standard_normal((B, 1, MH, MW))), 0, 48).astype(np.float32)).cuda()
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.time()
     fc.encode_async(lv); torch.cuda.synchronize(); t1 = time.time()
