@@ -65,6 +65,19 @@ def parse_args():
     return ap.parse_args()
 
 
+def split_for_streams(n, ns):
+    """sizes of the sub-batches of n images on ns streams: multiples of 16 where the list is long enough (the decode kernel takes two
+    samples per wave on the short corner diagonals when 16 divides the images per net), the remainder on the last stream; a list
+    shorter than 16 images stays on one stream (it is latency-bound: the per-plane chain is the same for 1 or 8 images)"""
+    if n < 16:
+        return [n] + [0] * (ns - 1)
+    blocks, rem = divmod(n, 16)
+    use = min(ns, blocks)
+    sizes = [16 * (blocks // use + (1 if i < blocks % use else 0)) for i in range(use)] + [0] * (ns - use)
+    sizes[use - 1] += rem
+    return sizes
+
+
 def synth_latents(batch, seed0, h=H, w=W):
     import numpy as np
     from util import latent
@@ -208,7 +221,8 @@ def run_rank(args):
         # BASELINE.json configs[3]: 64 images, image i -> rank i mod N, through the same codecs and streams
         mine = shard.shard_indices(64, rank, world)
         c4, m4, l4 = synth_latents(64, seed0=640000)
-        per = [mine[i::ns] for i in range(ns)]
+        sz4 = split_for_streams(len(mine), ns)
+        per = [mine[sum(sz4[:i]):sum(sz4[:i + 1])] for i in range(ns)]
         cd4 = [torch.from_numpy(c4[ix]).to(dev) if ix else torch.zeros((0, G, H, W), device=dev) for ix in per]
         mk4 = [torch.from_numpy(m4[ix]).to(dev) if ix else torch.zeros((0, G, H, W), device=dev) for ix in per]
         lv4 = [torch.from_numpy(l4[ix]).to(dev) if ix else torch.zeros((0, 1, H // 2, W // 2), device=dev) for ix in per]
