@@ -233,8 +233,11 @@ def run_rank(args):
                              "scaling": "strong", "note": "BASELINE.json configs[3]: fixed list of 64 images, image i -> rank i mod N, both streams"}
         # BASELINE.json configs[4]: LIC3602K 1024x2048 ERPs (48x128x256 latents, 32x64 -> 64x128 importance maps), model-idx 7 seed,
         # 16 images per stream through codecs of their own (decode order runs on 64-row windows there, DESIGN.md 4.1 b)
+        # (set-up may fail on one rank only, e.g. out of memory: the collective steps below run on every rank or on none)
+        H5, W5, B5 = 2 * H, 2 * W, 16
+        c5 = i5 = cd5 = mk5 = lv5 = None
+        err5 = None
         try:
-            H5, W5, B5 = 2 * H, 2 * W, 16
             l5, il5 = make_main_params(1000 * SSIM + 7, G), make_imp_params(1000 * SSIM + 7)
             c5 = [FusedCodec(G, H5, W5, max_batch=B5, device=local) for _ in range(ns)]
             i5 = [FusedImpCodec(H5 // 2, W5 // 2, max_batch=B5, device=local) for _ in range(ns)]
@@ -246,7 +249,10 @@ def run_rank(args):
             cd5 = [torch.from_numpy(cd[i * B5:(i + 1) * B5]).to(dev) for i in range(ns)]
             mk5 = [torch.from_numpy(mk[i * B5:(i + 1) * B5]).to(dev) for i in range(ns)]
             lv5 = [torch.from_numpy(lv[i * B5:(i + 1) * B5]).to(dev) for i in range(ns)]
-
+            torch.cuda.synchronize(dev)
+        except Exception as e:                                         # noqa: BLE001  (never lose the headline to a side figure)
+            err5 = repr(e)[:300]
+        if shard.all_ok(err5 is None, dev):
             def run5():
                 for ph in (0, 1):
                     for c, ic, a, b_, l_, st, ist in zip(c5, i5, cd5, mk5, lv5, streams, istreams):
@@ -262,10 +268,10 @@ def run_rank(args):
             extras["config5"] = {"images_per_gpu": B5 * ns, "ms": dt5 / 2 * 1e3, "value": world * B5 * ns * 4 * PIXELS / (dt5 / 2) / 1e6, "unit": "Mpixel/s",
                                  "roundtrip_exact": ok5, "mean_latent_bytes": float(np.mean([float(c.nbytes[:B5].float().mean().item()) for c in c5])),
                                  "note": "BASELINE.json configs[4]: 1024x2048 ERPs (48x128x256 latents), model-idx 7 seed, both streams, %d images on %d streams" % (B5 * ns, ns)}
-            del c5, i5, cd5, mk5, lv5
-            torch.cuda.empty_cache()
-        except Exception as e:                                         # noqa: BLE001  (never lose the headline to a side figure)
-            extras["config5"] = {"error": repr(e)[:300]}
+        else:
+            extras["config5"] = {"error": err5 or "set-up failed on another rank"}
+        del c5, i5, cd5, mk5, lv5
+        torch.cuda.empty_cache()
     ok = shard.all_ok(ok, dev)
 
     if rank == 0:
