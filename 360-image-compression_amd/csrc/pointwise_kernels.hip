@@ -298,8 +298,32 @@ LIC360_API int lic360_scale(void *stream, const float *x, float *out, long count
 }
 
 // ---------------------------------------------------------------------------- quant / dquant
-__global__ void k_quant_weight(const float *__restrict__ wb, float *__restrict__ wq, int total, int levels) {
-    GRID_STRIDE(i, total) wq[i] = (i % levels == 0) ? wb[i] : lic360_expf(wb[i]);        // quant_cuda.cu:35-43
+// (also clears the level counts: same size, one launch less than a memset of its own)
+__global__ void k_quant_weight(const float *__restrict__ wb, float *__restrict__ wq, float *__restrict__ count, int total, int levels) {
+    GRID_STRIDE(i, total) {
+        wq[i] = (i % levels == 0) ? wb[i] : lic360_expf(wb[i]);                           // quant_cuda.cu:35-43
+        count[i] = 0.0f;
+    }
+}
+// lic360_quant_one for levels <= 8 with the level increments in registers and no data-dependent loop: the subtractions stop at
+// the first negative remainder exactly as the loop's `break` does, so every float operation is the same one
+__device__ __forceinline__ int quant_one8(float x, const float (&w)[8], int levels, float *top) {
+    float tmp = x - w[0];
+    if (tmp < 0.0f) { *top = w[0]; return 0; }
+    int j = levels - 1;
+    float wj = w[0];                                                      // levels == 1: the loop below never runs
+    bool done = false;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        if (k < levels && !done) {
+            tmp -= w[k];
+            wj = w[k];
+            if (tmp < 0.0f) { done = true; j = k; }
+        }
+    }
+    if (tmp + tmp + wj < 0.0f) { tmp = tmp + wj; j--; }
+    *top = x - tmp;
+    return j;
 }
 __global__ void k_quant(const float *__restrict__ in, const float *__restrict__ wq, float *__restrict__ top, float *__restrict__ qidx,
                         float *__restrict__ count, long total, long inner, int C, int levels) {
@@ -384,13 +408,17 @@ __global__ __launch_bounds__(256) void k_dquant_plane4(const float *__restrict__
 // slab (n, c) per workgroup, 16 bytes per lane; per-thread level counts in 8-bit fields of one 64-bit register (levels <= 8,
 // at most 255 elements per thread between flushes), one LDS atomic per (thread, flush) and one global atomic per (slab, level)
 __global__ __launch_bounds__(256) void k_quant_slab4(const float *__restrict__ in, const float *__restrict__ wq, float *__restrict__ top,
-                                                     float *__restrict__ qidx, float *__restrict__ count, int inner4, int C, int levels) {
+                                                     float *__restrict__ qidx, float *__restrict__ count, int inner4, int C, int levels, int N, int nper) {
+    // workgroup (channel pc, sample group ng) walks the slabs (n, pc), n = ng * nper ..: the level counts are per channel, so the
+    // samples of a group share one flush and one set of global atomics
     __shared__ int hist[8];
-    const int pc = blockIdx.x % C;
+    const int pc = blockIdx.x % C, ng = blockIdx.x / C;
+    const int n_lo = ng * nper, n_hi = n_lo + nper < N ? n_lo + nper : N;
     if (threadIdx.x < 8) hist[threadIdx.x] = 0;
     __syncthreads();
-    const float *wl = wq + pc * levels;                                    // 8 floats, L1-resident (a register copy would be indexed dynamically)
-    const long base = (long)blockIdx.x * inner4;
+    float wl[8];                                                          // the channel's level increments (uniform address: scalar loads)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wl[k] = k < levels ? wq[pc * levels + k] : 0.0f;
     unsigned long long pk = 0;
     int since = 0;
     // per-thread 8-bit fields -> two registers of 16-bit fields, summed over the wave with 6 xor-shuffles, then 8 LDS atomics
@@ -418,7 +446,9 @@ __global__ __launch_bounds__(256) void k_quant_slab4(const float *__restrict__ i
         pk = 0;
         since = 0;
     };
+    for (int n = n_lo; n < n_hi; ++n)
     for (int i0 = 0; i0 < inner4; i0 += 256) {                            // uniform trip count: flush() shuffles across the wave
+        const long base = ((long)n * C + pc) * inner4;
         const int i = i0 + threadIdx.x;
         if (i < inner4) {
             const f4 v = ((const f4 *)in)[base + i];
@@ -426,7 +456,7 @@ __global__ __launch_bounds__(256) void k_quant_slab4(const float *__restrict__ i
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float tt;
-                const int j = lic360_quant_one(v[k], wl, levels, &tt);
+                const int j = quant_one8(v[k], wl, levels, &tt);
                 t[k] = tt;
                 q[k] = (float)j;
                 pk += 1ull << (8 * j);
@@ -445,11 +475,15 @@ LIC360_API int lic360_quant(void *stream, const float *x, const float *weight_b,
                             int n, int c, int h, int w, int levels) {
     ARG_CHECK(x && weight_b && wq && top && count && n > 0 && c > 0 && levels > 0);
     long inner = (long)h * w, total = (long)n * c * inner;
-    HIP_TRY(hipMemsetAsync(count, 0, sizeof(float) * (size_t)c * levels, (hipStream_t)stream));
-    hipLaunchKernelGGL(k_quant_weight, dim3(lic360_blocks(c * levels)), dim3(256), 0, (hipStream_t)stream, weight_b, wq, c * levels, levels);
+    hipLaunchKernelGGL(k_quant_weight, dim3(lic360_blocks(c * levels)), dim3(256), 0, (hipStream_t)stream, weight_b, wq, count, c * levels, levels);
     const bool al16 = inner % 4 == 0 && (((uintptr_t)x | (uintptr_t)top | (uintptr_t)qidx) & 15) == 0;
     if (levels <= 8 && al16 && (long)n * c < (1l << 30) && inner / 4 < (1l << 30))
-        hipLaunchKernelGGL(k_quant_slab4, dim3((unsigned)(n * c)), dim3(256), 0, (hipStream_t)stream, x, wq, top, qidx, count, (int)(inner / 4), c, levels);
+    {
+        const int nper = 1;                                               // (several samples per workgroup were measured: slower)
+        const int ngroups = (n + nper - 1) / nper;
+        hipLaunchKernelGGL(k_quant_slab4, dim3((unsigned)(c * ngroups)), dim3(256), 0, (hipStream_t)stream, x, wq, top, qidx, count, (int)(inner / 4), c,
+                           levels, n, nper);
+    }
     else if (levels <= 64 && (long)n * c < (1l << 30))
         hipLaunchKernelGGL(k_quant_slab, dim3((unsigned)(n * c)), dim3(256), 0, (hipStream_t)stream, x, wq, top, qidx, count, inner, c, levels);
     else

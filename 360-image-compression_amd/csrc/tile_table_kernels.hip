@@ -122,22 +122,30 @@ LIC360_API int lic360_tile_add(void *stream, float *y, const float *x, int n, in
 
 // ---------------------------------------------------------------------------- A14 GMM CDF table
 // One lane per symbol.  w/d rewritten in place (softmax / sigma floor) as the reference does.
-template <int MAXG>
+// CNG / CNSTEP > 0 fix the mixture size and the alphabet at compile time (3 and 8 for the latent model): every array then lives
+// in registers; with run-time bounds the dynamically indexed arrays go to scratch memory.
+template <int MAXG, int CNG, int CNSTEP>
 __global__ void k_gmm_table(float *__restrict__ w, float *__restrict__ d, const float *__restrict__ m, float *__restrict__ out,
-                            int tn, int ng, int nstep, float bias, float total, float beta) {
+                            int tn, int ng_, int nstep_, float bias, float total, float beta) {
+    const int ng = CNG ? CNG : ng_, nstep = CNSTEP ? CNSTEP : nstep_;
     GRID_STRIDE(n, tn) {
-        float lw[MAXG], ld[MAXG], lm[MAXG];
+        float lw[CNG ? CNG : MAXG], ld[CNG ? CNG : MAXG], lm[CNG ? CNG : MAXG];
+#pragma unroll
         for (int i = 0; i < ng; ++i) { lw[i] = w[n * ng + i]; ld[i] = d[n * ng + i]; lm[i] = m[n * ng + i]; }
         lic360_softmax_inplace(lw, ng);
+#pragma unroll
         for (int i = 0; i < ng; ++i) ld[i] = lic360_sigma_floor(ld[i], beta);
+#pragma unroll
         for (int i = 0; i < ng; ++i) { w[n * ng + i] = lw[i]; d[n * ng + i] = ld[i]; }
         float *T = out + n * (nstep + 1);
         // nstep <= 16 rows live in registers for the fix-up
-        float t[17];
+        float t[CNSTEP ? CNSTEP + 1 : 17];
         t[0] = 0.0f;
         t[nstep] = (float)(int)total;
+#pragma unroll
         for (int pt = 1; pt < nstep; ++pt) t[pt] = (float)lic360_gmm_cdf_entry(pt, bias, total, lw, ld, lm, ng);
         lic360_cdf_fixup(t, nstep, 0);
+#pragma unroll
         for (int pt = 0; pt <= nstep; ++pt) T[pt] = t[pt];
     }
 }
@@ -145,7 +153,10 @@ LIC360_API int lic360_gmm_table(void *stream, float *w, float *d, const float *m
                                 float bias, float total, float beta) {
     ARG_CHECK(w && d && m && out && tn >= 0 && ng >= 1 && ng <= 16 && nstep >= 1 && nstep <= 16);
     if (tn == 0) return 0;
-    hipLaunchKernelGGL(k_gmm_table<16>, dim3(lic360_blocks(tn)), dim3(256), 0, (hipStream_t)stream, w, d, m, out, tn, ng, nstep, bias, total, beta);
+    if (ng == 3 && nstep == 8)
+        hipLaunchKernelGGL((k_gmm_table<16, 3, 8>), dim3(lic360_blocks(tn)), dim3(256), 0, (hipStream_t)stream, w, d, m, out, tn, ng, nstep, bias, total, beta);
+    else
+        hipLaunchKernelGGL((k_gmm_table<16, 0, 0>), dim3(lic360_blocks(tn)), dim3(256), 0, (hipStream_t)stream, w, d, m, out, tn, ng, nstep, bias, total, beta);
     LAUNCH_CHECK();
     return 0;
 }

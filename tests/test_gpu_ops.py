@@ -292,6 +292,21 @@ def test_dtow_impmap_quant(lic):
     assert np.array_equal(host(lic.DquantOp(C, 8, 0, False).forward(dev(rq), dev(msk), dev(wb))[0]), orc.dquant(rq, msk, wb))
 
 
+@pytest.mark.parametrize("levels,N,C,H,W", [(8, 3, 5, 8, 12), (2, 2, 3, 4, 4), (3, 1, 7, 6, 10), (5, 2, 4, 5, 7), (8, 1, 2, 40, 64), (12, 2, 3, 4, 8)])
+def test_quant_levels_and_ranges(lic, levels, N, C, H, W):
+    """the nearest-centre search for every alphabet size (<= 8 levels: increments in registers, no data-dependent loop; more: the
+    generic kernels), 16-byte aligned and unaligned planes, values below the first centre, between centres and beyond the last one"""
+    rng = np.random.default_rng(100 * levels + H)
+    wb = np.concatenate([rng.uniform(-1, 0, (C, 1)), rng.uniform(-2, 0.3, (C, levels - 1))], 1).astype(np.float32)
+    span = float(np.exp(wb[:, 1:]).sum(1).max()) + 2.0
+    x = rng.uniform(-2.0, span, (N, C, H, W)).astype(np.float32)
+    x.reshape(-1)[::7] = np.repeat(wb[:, 0], N * H * W).reshape(C, -1).T.reshape(-1)[:x.size][::7]      # exact centres too
+    q = lic.QuantOp(C, levels, 0.9, 100, 2, 0.1, 0, False)
+    top, qidx = q.forward(dev(x), dev(wb), dev(np.zeros((C, levels), np.float32)), False)
+    rt, rq, rc = orc.quant(x, wb)
+    assert np.array_equal(host(top), rt) and np.array_equal(host(qidx), rq) and np.array_equal(host(q.count_data_), rc)
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
