@@ -289,6 +289,23 @@ LIC360_API int lic360_imp2mask(void *stream, const float *x, float *out, int n, 
     LAUNCH_CHECK();
     return 0;
 }
+// MaskConstrainOp (training-side helper of MaskConv2, extension/mask_constrain_cuda.cu:17-41): in place, tiny
+__global__ void k_mask_constrain(float *__restrict__ w, long total, int channel, int sz, int group_in, int group_out, int strict) {
+    GRID_STRIDE(i, total) {
+        const int tw = (int)(i % sz), th = (int)((i / sz) % sz);
+        const int tc = (int)((i / sz / sz) % channel) / group_in, tn = (int)(i / sz / sz / channel) / group_out;
+        const int lhs = tw + th + tc, rhs = tn + sz - 1;
+        if (strict ? lhs > rhs : lhs >= rhs) w[i] = 0.0f;
+    }
+}
+LIC360_API int lic360_mask_constrain(void *stream, float *weight, int nout, int channel, int ksz, int ngroup, int constrain) {
+    ARG_CHECK(weight && nout > 0 && channel > 0 && ksz > 0 && ngroup > 0 && nout % ngroup == 0 && channel % ngroup == 0 && (constrain == 5 || constrain == 6));
+    const long total = (long)nout * channel * ksz * ksz;
+    hipLaunchKernelGGL(k_mask_constrain, dim3(lic360_blocks(total)), dim3(256), 0, (hipStream_t)stream, weight, total, channel, ksz, channel / ngroup,
+                       nout / ngroup, constrain == 6 ? 1 : 0);
+    LAUNCH_CHECK();
+    return 0;
+}
 LIC360_API int lic360_scale(void *stream, const float *x, float *out, long count, float bias, float scale) {
     ARG_CHECK(x && out && count >= 0);
     if (count == 0) return 0;

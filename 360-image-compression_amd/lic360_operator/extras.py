@@ -9,7 +9,7 @@ metric / bookkeeping utilities, and two wrappers of out-of-scope native ops) and
   ModuleSaver    best / latest checkpoint writer (lic360_operator/ModuleSaver.py:4-35)
   Logger         screen + file log (lic360_operator/Logger.py:3-23)
   MultiProject   needs lic360.ProjectsOp  (viewport metrics)  -> raises on construction
-  MaskConv2      needs lic360.MaskConstrainOp (training)      -> raises on construction
+  MaskConv2      torch conv2d over a weight masked by lic360.MaskConstrainOp (the training-time form of the context conv)
 """
 import math
 import os
@@ -163,8 +163,35 @@ class MultiProject(nn.Module):
                                   "extension/projects_cuda.cu): viewport metrics are outside the accelerated path (SURVEY.md §8f.3)")
 
 
+class _MaskConstrainFn(torch.autograd.Function):
+    """identity on the tensor it is given, after masking it in place; the gradient is masked the same way"""
+    @staticmethod
+    def forward(ctx, x, op):
+        op[x.device.index].forward(x)
+        ctx.op = op
+        return x
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        ctx.op[grad_output.device.index].backward(grad_output)
+        return grad_output, None
+
+
 class MaskConv2(nn.Module):
+    """The training-time form of the group-causal context convolution (reference lic360_operator/MaskConstrain.py:24-39): a dense
+    `conv2d` whose weight is masked by lic360.MaskConstrainOp before every forward.  Same constructor, same parameter names
+    (`weight` [c_out*ngroup, c_in*ngroup, k, k], `bias`), so checkpoints interchange; the inference path evaluates the same
+    function with CconvEc / CconvDc."""
     def __init__(self, ngroup, c_in, c_out, kernel_size, hidden=False, device=0, time_it=False):
         super().__init__()
-        raise NotImplementedError("MaskConv2 wraps lic360.MaskConstrainOp (training-time weight masking, "
-                                  "extension/mask_constrain_cuda.cu): training is outside the accelerated path (SURVEY.md §8f.4)")
+        import lic360
+        devs = [device] if isinstance(device, int) else list(device)
+        self.op = {gid: lic360.MaskConstrainOp(6 if hidden else 5, ngroup, gid, time_it) for gid in devs}
+        self.weight = nn.Parameter(torch.empty((c_out * ngroup, c_in * ngroup, kernel_size, kernel_size), dtype=torch.float32))
+        nn.init.kaiming_normal_(self.weight)
+        self.bias = nn.Parameter(torch.zeros(c_out * ngroup, dtype=torch.float32))
+        self.pad = kernel_size // 2
+
+    def forward(self, x):
+        self.weight.data = _MaskConstrainFn.apply(self.weight.data, self.op)
+        return nn.functional.conv2d(x, self.weight, self.bias, padding=self.pad)

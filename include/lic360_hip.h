@@ -44,6 +44,10 @@ int lic360_imp_map(void *stream, const float *x, const float *imp, float *out, f
 int lic360_imp_map_constrain(void *stream, float *constrain, int n, int h, float rt, float scale_constrain);
 /* Imp2maskOp.forward                         extension/imp2mask_cuda.cu:41-57 */
 int lic360_imp2mask(void *stream, const float *x, float *out, int n, int c, int h, int w, int cpn);
+/* MaskConstrainOp.forward / .backward (in place on a conv weight or its gradient [nout][channel][ksz][ksz]; constrain 5: taps with
+ * tw + th + tc >= tn + ksz - 1 are zeroed, 6: tw + th + tc > tn + ksz - 1; tc / tn = input / output group)
+ *                                            extension/mask_constrain_cuda.cu:17-41,47-91 */
+int lic360_mask_constrain(void *stream, float *weight, int nout, int channel, int ksz, int ngroup, int constrain);
 /* ScaleOp.forward                            extension/scale_cuda.cu:32-48 */
 int lic360_scale(void *stream, const float *x, float *out, long count, float bias, float scale);
 /* QuantOp.forward (train=false path); qidx may be NULL; wq_scratch/count are [c,levels] device buffers

@@ -462,6 +462,17 @@ ORC_API void orc_imp2mask(const float *in, float *out, int N, int C, int H, int 
         out[i] = pc < imp ? 1.0f : 0.0f;
     }
 }
+/* MaskConstrainOp.forward / .backward: zero the non-causal taps of a group-structured conv weight [nout][channel][sz][sz] in place
+ * (extension/mask_constrain_cuda.cu:17-41; v5: tw + th + tc >= tn + sz - 1, v6: >) */
+ORC_API void orc_mask_constrain(float *w, int nout, int channel, int sz, int ngroup, int constrain) {
+    const int group_in = channel / ngroup, group_out = nout / ngroup;
+    const long total = (long)nout * channel * sz * sz;
+    for (long index = 0; index < total; ++index) {
+        const int tw = (int)(index % sz), th = (int)((index / sz) % sz);
+        const int tc = (int)((index / sz / sz) % channel) / group_in, tn = (int)(index / sz / sz / channel) / group_out;
+        if (constrain == 5 ? (tw + th + tc >= tn + sz - 1) : (tw + th + tc > tn + sz - 1)) w[index] = 0.0f;
+    }
+}
 ORC_API void orc_scale(const float *in, float *out, long n, float bias, float scale) {
     for (long i = 0; i < n; ++i) out[i] = lic360_affine(in[i], scale, bias);
 }

@@ -180,6 +180,7 @@ lib.orc_sphere_lat_scale.argtypes = [_f, _f, _f] + [C.c_int] * 4
 lib.orc_imp_map.argtypes = [_f, _f, _f, _PF] + [C.c_int] * 5
 lib.orc_imp_map_constrain.argtypes = [_f, C.c_int, C.c_int, C.c_float, C.c_float]
 lib.orc_imp2mask.argtypes = [_f, _f] + [C.c_int] * 5
+lib.orc_mask_constrain.argtypes = [_f] + [C.c_int] * 5
 lib.orc_scale.argtypes = [_f, _f, C.c_long, C.c_float, C.c_float]
 lib.orc_quant.argtypes = [_f, _f, _f, _PF, _f] + [C.c_int] * 5
 lib.orc_dquant.argtypes = [_f, _f, _f, _f] + [C.c_int] * 5
@@ -253,6 +254,13 @@ def imp2mask(x, levels, channels):
     N, _, H, W = x.shape
     out = np.empty((N, channels, H, W), np.float32)
     lib.orc_imp2mask(f32(x), out, N, channels, H, W, channels // levels)
+    return out
+
+
+def mask_constrain(w, ngroup, constrain):
+    """-> masked copy of w [nout, channel, k, k]"""
+    out = np.ascontiguousarray(w, dtype=np.float32).copy()
+    lib.orc_mask_constrain(out, out.shape[0], out.shape[1], out.shape[2], ngroup, constrain)
     return out
 
 

@@ -307,6 +307,43 @@ def test_quant_levels_and_ranges(lic, levels, N, C, H, W):
     assert np.array_equal(host(top), rt) and np.array_equal(host(qidx), rq) and np.array_equal(host(q.count_data_), rc)
 
 
+@pytest.mark.parametrize("ngroup,c_in,c_out,k,hidden", [(6, 4, 4, 5, True), (6, 1, 4, 5, False), (1, 8, 5, 5, True), (4, 3, 2, 3, False), (48, 4, 3, 5, True)])
+def test_mask_constrain_and_maskconv2(lic, ngroup, c_in, c_out, k, hidden):
+    """MaskConstrainOp zeroes exactly the taps the oracle's rule zeroes (forward on a weight, backward on a gradient, in place), and
+    MaskConv2 -- torch's own conv2d over the masked weight, the training-time form of the context model -- agrees with the CconvEc
+    kernel on the same weights (different summation order: 1e-4)."""
+    import lic360_operator as lo
+    rng = np.random.default_rng(ngroup * 10 + k)
+    constrain = 6 if hidden else 5
+    w = rng.standard_normal((c_out * ngroup, c_in * ngroup, k, k)).astype(np.float32)
+    op = lic.MaskConstrainOp(constrain, ngroup, 0, False)
+    wd = dev(w)
+    assert op.forward(wd) is None and np.array_equal(host(wd), orc.mask_constrain(w, ngroup, constrain))
+    gd = dev(w[::-1].copy())
+    op.backward(gd)
+    assert np.array_equal(host(gd), orc.mask_constrain(w[::-1].copy(), ngroup, constrain))
+    if k != 5:
+        return                                                              # the context kernels are 5 x 5
+    mc = lo.MaskConv2(ngroup, c_in, c_out, k, hidden, 0).to("cuda:0")
+    x = dev(rng.standard_normal((2, c_in * ngroup, 9, 13)).astype(np.float32))
+    with torch.no_grad():
+        mc.bias.copy_(dev(rng.standard_normal(c_out * ngroup).astype(np.float32)))
+        y = mc(x)
+        assert np.array_equal(host(mc.weight), orc.mask_constrain(host(mc.weight), ngroup, constrain))      # masked in place, idempotent
+        ec = lo.CconvEc(ngroup, c_in, c_out, k, hidden, False, 0).to("cuda:0")
+        ec.weight.copy_(mc.weight)
+        ec.bias.copy_(mc.bias)
+        z = ec(x)
+    assert torch.allclose(y, z, rtol=1e-4, atol=1e-4), float((y - z).abs().max())
+    # (as in the reference, the mask is applied to `weight.data`: dead taps do receive gradients and are zeroed again by the next forward)
+    mc.zero_grad()
+    mc(x).sum().backward()
+    with torch.no_grad():
+        mc.weight.add_(mc.weight.grad, alpha=-0.1)
+        mc(x)
+    assert np.array_equal(host(mc.weight), orc.mask_constrain(host(mc.weight), ngroup, constrain))
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)

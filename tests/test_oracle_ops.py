@@ -169,3 +169,15 @@ def test_oracle_codec_roundtrip_small():
     lv = rng.integers(0, 9, (1, 1, 4, 6)).astype(np.float32)
     il = rc.make_imp_params(12, cpg=24, nsym=9)
     assert np.array_equal(rc.decode_imp(rc.encode_imp(lv, il, nsym=9), il, 4, 6, nsym=9), lv)
+
+
+@pytest.mark.parametrize("ngroup,c_in,c_out,k,constrain", [(6, 4, 4, 5, 6), (6, 1, 4, 5, 5), (1, 8, 5, 5, 6), (4, 3, 2, 3, 5)])
+def test_mask_constrain_rule(ngroup, c_in, c_out, k, constrain):
+    """orc_mask_constrain against the rule written out with numpy index grids (extension/mask_constrain_cuda.cu:17-41)"""
+    rng = np.random.default_rng(k + ngroup)
+    w = rng.standard_normal((c_out * ngroup, c_in * ngroup, k, k)).astype(np.float32)
+    tn = (np.arange(c_out * ngroup) // c_out)[:, None, None, None]
+    tc = (np.arange(c_in * ngroup) // c_in)[None, :, None, None]
+    th, tw = np.arange(k)[None, None, :, None], np.arange(k)[None, None, None, :]
+    dead = (tw + th + tc >= tn + k - 1) if constrain == 5 else (tw + th + tc > tn + k - 1)
+    assert np.array_equal(orc.mask_constrain(w, ngroup, constrain), np.where(dead, np.float32(0), w))
