@@ -223,6 +223,65 @@ LIC360_API int lic360_sphere_cut_edge(void *stream, const float *x, float *out, 
     LAUNCH_CHECK();
     return 0;
 }
+// ---- training-side gradients of the sphere ops.  One output element per thread; the reference's order of additions.
+// STRIDED: the interior of a padded tensor (in-place form), pitch = w + 2 pad
+template <bool INPLACE>
+__global__ void k_sphere_pad_backward(float *__restrict__ in_diff, const float *top_diff, long total, int H, int W, int pad) {
+    const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    GRID_STRIDE(i, total) {
+        const int pw = (int)(i % W), ph = (int)((i / W) % H);
+        const long pn = i / W / H;
+        int th = ph + pad, tw = pw + pad;
+        const long t = (pn * Ho + th) * Wo + tw;
+        float v = top_diff[t];
+        const bool edge_w = pw < pad || pw >= W - pad;
+        if (edge_w) {
+            tw = pw < pad ? pw + W + pad : pw - W + pad;
+            v += top_diff[(pn * Ho + th) * Wo + tw];
+        }
+        if (ph < pad || ph >= H - pad) {
+            th = ph < pad ? pad - ph - 1 : (2 * H - 1 - ph) + pad;
+            tw = W - 1 - pw + pad;
+            v += top_diff[(pn * Ho + th) * Wo + tw];
+            if (edge_w) {
+                tw = pw < pad ? pad - pw - 1 : 2 * W - pw - 1 + pad;
+                v += top_diff[(pn * Ho + th) * Wo + tw];
+            }
+        }
+        if constexpr (INPLACE) in_diff[t] = v;              // interior cell of the same buffer: apron cells are only ever read
+        else in_diff[i] = v;
+    }
+}
+LIC360_API int lic360_sphere_pad_backward(void *stream, float *in_diff, const float *top_diff, int nc, int h, int w, int pad) {
+    ARG_CHECK(in_diff && top_diff && nc > 0 && pad >= 0 && h >= pad && w >= pad && h > 0 && w > 0);
+    const long total = (long)nc * h * w;
+    hipLaunchKernelGGL(k_sphere_pad_backward<false>, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, in_diff, top_diff, total, h, w, pad);
+    LAUNCH_CHECK();
+    return 0;
+}
+LIC360_API int lic360_sphere_pad_backward_inplace(void *stream, float *diff, int nc, int hp, int wp, int pad) {
+    ARG_CHECK(diff && nc > 0 && pad >= 0 && hp > 2 * pad && wp > 2 * pad && hp - 2 * pad >= pad && wp - 2 * pad >= pad);
+    const int h = hp - 2 * pad, w = wp - 2 * pad;
+    const long total = (long)nc * h * w;
+    hipLaunchKernelGGL(k_sphere_pad_backward<true>, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, diff, diff, total, h, w, pad);
+    LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_sphere_cut_edge_backward(float *__restrict__ in_diff, const float *__restrict__ top_diff, long total, int H, int W, int pad) {
+    const int Ho = H - 2 * pad, Wo = W - 2 * pad;
+    GRID_STRIDE(i, total) {
+        const int pw = (int)(i % W), ph = (int)((i / W) % H);
+        const long pn = i / W / H;
+        in_diff[i] = (pw < pad || pw >= Wo + pad || ph < pad || ph >= Ho + pad) ? 0.0f : top_diff[(pn * Ho + ph - pad) * Wo + pw - pad];
+    }
+}
+LIC360_API int lic360_sphere_cut_edge_backward(void *stream, float *in_diff, const float *top_diff, int nc, int h, int w, int pad) {
+    ARG_CHECK(in_diff && top_diff && nc > 0 && pad >= 0 && h > 2 * pad && w > 2 * pad);
+    const long total = (long)nc * h * w;
+    hipLaunchKernelGGL(k_sphere_cut_edge_backward, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, in_diff, top_diff, total, h, w, pad);
+    LAUNCH_CHECK();
+    return 0;
+}
 LIC360_API int lic360_sphere_lat_scale(void *stream, const float *x, const float *weight, float *out, int nc, int h, int w, int npart) {
     ARG_CHECK(x && weight && out && nc > 0 && npart > 0 && h % npart == 0);
     long total = (long)nc * h * w;
@@ -280,6 +339,81 @@ LIC360_API int lic360_imp_map_constrain(void *stream, float *constrain, int n, i
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     free(buf);
     HIP_TRY(e);
+    return 0;
+}
+LIC360_API int lic360_imp_map_alpha(void *stream, float *alpha_t, int h, float alpha, float sw) {
+    ARG_CHECK(alpha_t && h > 0);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)h);
+    float pi = (float)acos(-1.0), mx = 0.0f;
+    for (int i = 0; i < h; ++i) {
+        float v = (float)cos((double)(float)((0.5 - ((double)i + 0.5) / (double)h) * (double)pi));
+        buf[i] = v < 0 ? -v : v;
+        if (buf[i] > mx) mx = buf[i];
+    }
+    for (int i = 0; i < h; ++i) {
+        float t = buf[i] / mx;
+        t = t * sw; t = t + 1.0f; t = t - sw;
+        buf[i] = alpha / t;
+    }
+    hipError_t e = hipMemcpyAsync(alpha_t, buf, sizeof(float) * (size_t)h, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    free(buf);
+    HIP_TRY(e);
+    return 0;
+}
+// ImpMapOp.backward (training side)
+__global__ void k_imp_map_backward_data(const float *__restrict__ top_diff, const float *__restrict__ imp, float *__restrict__ data_diff, long total,
+                                        long inner, int C, int levels, int cpl) {
+    GRID_STRIDE(i, total) {
+        const long ps = i % inner, pn = i / inner / C;
+        const int pc = (int)((i / inner) % C);
+        const int ch = (int)floor((double)(imp[pn * inner + ps] * (float)levels)) * cpl;       // no epsilon here (imp_map_cuda.cu:147)
+        data_diff[i] = pc < ch ? top_diff[i] : 0.0f;
+    }
+}
+__global__ void k_imp_map_backward_imp(const float *__restrict__ top_diff, const float *__restrict__ imp, const float *__restrict__ sphere_constrain,
+                                       const float *__restrict__ alpha_t, float *__restrict__ imp_diff, long count, long inner, int C, int W,
+                                       int levels, int cpl, int imp_kernel, float gamma) {
+    GRID_STRIDE(index, count) {
+        const long ps = index % inner, pn = index / inner;
+        const int ph = (int)(ps / W);
+        const float sc = sphere_constrain[index / W];
+        const int ch = (int)((double)(imp[index] * (float)levels) + 0.00001) * cpl;
+        if (imp_kernel == 3) {                                                                 // v4: sign of (arg max of the running gain) - level
+            const float decay = sc < 0 ? 0.1f : 1.0f, cost = alpha_t[ph];
+            long base = pn * C * inner + ps;
+            float tmp = 0.0f, tmax = -10000.0f;
+            int target = 0;
+            for (int i = 0; i < C; ++i) {
+                tmp = tmp + fabsf(top_diff[base]) - cost * decay;
+                base += inner;
+                if (tmp > tmax) { tmax = tmp; target = i; }
+            }
+            imp_diff[index] = target < ch ? gamma : (target > ch ? -gamma : 0.0f);
+        } else {                                                                               // v1 / v2 / v3
+            const int c0 = imp_kernel == 2 ? 0 : ch;
+            long base = (pn * C + c0) * inner + ps;
+            float diff = 0.0f;
+            if (sc > 0) diff = imp_kernel == 0 ? alpha_t[ph] * (float)(C - ch) : alpha_t[ph];
+            for (int i = c0; i < C; ++i) {
+                diff -= fabsf(top_diff[base]);
+                base += inner;
+            }
+            imp_diff[index] = diff;
+        }
+    }
+}
+LIC360_API int lic360_imp_map_backward(void *stream, const float *top_diff, const float *imp, const float *sphere_constrain, const float *alpha_t,
+                                       float *data_diff, float *imp_diff, int n, int c, int h, int w, int levels, int imp_kernel, float gamma) {
+    ARG_CHECK(top_diff && imp && sphere_constrain && alpha_t && data_diff && imp_diff && n > 0 && c > 0 && h > 0 && w > 0 && levels > 0 && c % levels == 0 &&
+              imp_kernel >= 0);
+    const long inner = (long)h * w, total = (long)n * c * inner, count = (long)n * inner;
+    hipLaunchKernelGGL(k_imp_map_backward_data, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, top_diff, imp, data_diff, total, inner, c,
+                       levels, c / levels);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_imp_map_backward_imp, dim3(lic360_blocks(count)), dim3(256), 0, (hipStream_t)stream, top_diff, imp, sphere_constrain, alpha_t,
+                       imp_diff, count, inner, c, w, levels, c / levels, imp_kernel > 3 ? 0 : imp_kernel, gamma);
+    LAUNCH_CHECK();
     return 0;
 }
 LIC360_API int lic360_imp2mask(void *stream, const float *x, float *out, int n, int c, int h, int w, int cpn) {

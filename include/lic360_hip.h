@@ -34,6 +34,14 @@ int lic360_sphere_pad_inplace(void *stream, float *x, int nc, int hp, int wp, in
 int lic360_sphere_trim(void *stream, float *x, int nc, int h, int w, int pad);
 /* SphereCutEdgeOp.forward                    extension/sphere_cut_edge_cuda.cu:43-62 */
 int lic360_sphere_cut_edge(void *stream, const float *x, float *out, int nc, int h, int w, int pad);
+/* SpherePadOp.backward: gradient of the un-padded tensor [nc][h][w] from top_diff [nc][h+2p][w+2p]: own cell + wrap column + mirrored pole
+ * row + pole corner, added in that order     extension/sphere_pad_cuda.cu:107-136,181-198 */
+int lic360_sphere_pad_backward(void *stream, float *in_diff, const float *top_diff, int nc, int h, int w, int pad);
+/* SpherePadOp.backward, inplace=true: interior cells of diff [nc][hp][wp] accumulate their apron copies, the apron stays
+ *                                            extension/sphere_pad_cuda.cu:138-180 */
+int lic360_sphere_pad_backward_inplace(void *stream, float *diff, int nc, int hp, int wp, int pad);
+/* SphereCutEdgeOp.backward: in_diff [nc][h][w] = top_diff [nc][h-2p][w-2p] inside a zero apron   extension/sphere_cut_edge_cuda.cu:63-96 */
+int lic360_sphere_cut_edge_backward(void *stream, float *in_diff, const float *top_diff, int nc, int h, int w, int pad);
 /* SphereLatScaleOp.forward / backward (same product)  extension/sphere_lat_scale_cuda.cu:40-58,69-87 */
 int lic360_sphere_lat_scale(void *stream, const float *x, const float *weight, float *out, int nc, int h, int w, int npart);
 
@@ -42,6 +50,14 @@ int lic360_sphere_lat_scale(void *stream, const float *x, const float *weight, f
 int lic360_imp_map(void *stream, const float *x, const float *imp, float *out, float *mask, int n, int c, int h, int w, int levels);
 /* ImpMapOp constraint tensor top[1]          extension/imp_map_cuda.cu:27-71 (host computes, device write) */
 int lic360_imp_map_constrain(void *stream, float *constrain, int n, int h, float rt, float scale_constrain);
+/* alpha_t [h] of ImpMapOp: alpha / (|cos((0.5-(i+0.5)/h) pi)| / max * scale_weight + 1 - scale_weight) (host computes, device write)
+ *                                            extension/imp_map_cuda.cu:27-36,49-52 */
+int lic360_imp_map_alpha(void *stream, float *alpha_t, int h, float alpha, float scale_weight);
+/* ImpMapOp.backward: data_diff [n,c,h,w] = top_diff under the mask floor(imp*levels); imp_diff [n,1,h,w] by rule imp_kernel 0..3
+ * (kernels v1..v4), channel sums in ascending order; sphere_constrain [n,h], alpha_t [h]
+ *                                            extension/imp_map_cuda.cu:138-298 */
+int lic360_imp_map_backward(void *stream, const float *top_diff, const float *imp, const float *sphere_constrain, const float *alpha_t,
+                            float *data_diff, float *imp_diff, int n, int c, int h, int w, int levels, int imp_kernel, float gamma);
 /* Imp2maskOp.forward                         extension/imp2mask_cuda.cu:41-57 */
 int lic360_imp2mask(void *stream, const float *x, float *out, int n, int c, int h, int w, int cpn);
 /* MaskConstrainOp.forward / .backward (in place on a conv weight or its gradient [nout][channel][ksz][ksz]; constrain 5: taps with

@@ -399,6 +399,67 @@ ORC_API void orc_sphere_trim(float *data, int NC, int H, int W, int pad) {
     }
 }
 /* sphere_cut_edge_forward_kernel             extension/sphere_cut_edge_cuda.cu:31-41 */
+/* SpherePadOp.backward, not in place: the gradient of an interior cell is its own cell of top_diff plus the apron cells that were
+ * copied from it -- wrap columns, then pole rows (mirrored), then the pole corner -- added in that order
+ * (extension/sphere_pad_cuda.cu:107-136).  in_diff [NC][H][W], top_diff [NC][H+2p][W+2p]. */
+ORC_API void orc_sphere_pad_backward(float *in_diff, const float *top_diff, int NC, int H, int W, int pad) {
+    const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    for (long index = 0; index < (long)NC * H * W; ++index) {
+        const int pw = (int)(index % W), ph = (int)((index / W) % H);
+        const long pn = index / W / H;
+        int th = ph + pad, tw = pw + pad;
+        float v = top_diff[(pn * Ho + th) * Wo + tw];
+        if (pw < pad || pw >= W - pad) {
+            tw = pw < pad ? pw + W + pad : pw - W + pad;
+            v += top_diff[(pn * Ho + th) * Wo + tw];
+        }
+        if (ph < pad || ph >= H - pad) {
+            th = ph < pad ? pad - ph - 1 : (2 * H - 1 - ph) + pad;
+            tw = W - 1 - pw + pad;
+            v += top_diff[(pn * Ho + th) * Wo + tw];
+            if (pw < pad || pw >= W - pad) {
+                tw = pw < pad ? pad - pw - 1 : 2 * W - pw - 1 + pad;
+                v += top_diff[(pn * Ho + th) * Wo + tw];
+            }
+        }
+        in_diff[index] = v;
+    }
+}
+/* ... in place (inplace=true): the interior cells of the padded gradient accumulate their apron copies; the apron itself is left as it
+ * is (extension/sphere_pad_cuda.cu:138-165).  diff [NC][Hp][Wp], Hp = H + 2p */
+ORC_API void orc_sphere_pad_backward_inplace(float *diff, int NC, int Hp, int Wp, int pad) {
+    const int H = Hp - 2 * pad, W = Wp - 2 * pad;
+    for (long index = 0; index < (long)NC * H * W; ++index) {
+        const int pw = (int)(index % W), ph = (int)((index / W) % H);
+        const long pn = index / W / H;
+        int th = ph + pad, tw = pw + pad;
+        const long t = (pn * Hp + th) * Wp + tw;
+        float v = diff[t];
+        if (pw < pad || pw >= W - pad) {
+            tw = pw < pad ? pw + W + pad : pw - W + pad;
+            v += diff[(pn * Hp + th) * Wp + tw];
+        }
+        if (ph < pad || ph >= H - pad) {
+            th = ph < pad ? pad - ph - 1 : (2 * H - 1 - ph) + pad;
+            tw = W - 1 - pw + pad;
+            v += diff[(pn * Hp + th) * Wp + tw];
+            if (pw < pad || pw >= W - pad) {
+                tw = pw < pad ? pad - pw - 1 : 2 * W - pw - 1 + pad;
+                v += diff[(pn * Hp + th) * Wp + tw];
+            }
+        }
+        diff[t] = v;                                       /* interior cells only: no cell read above is ever written */
+    }
+}
+/* SphereCutEdgeOp.backward: zero apron around the gradient (extension/sphere_cut_edge_cuda.cu:63-78).  in_diff [NC][H][W] */
+ORC_API void orc_sphere_cut_edge_backward(float *in_diff, const float *top_diff, int NC, int H, int W, int pad) {
+    const int Ho = H - 2 * pad, Wo = W - 2 * pad;
+    for (long index = 0; index < (long)NC * H * W; ++index) {
+        const int pw = (int)(index % W), ph = (int)((index / W) % H);
+        const long pn = index / W / H;
+        in_diff[index] = (pw < pad || pw >= Wo + pad || ph < pad || ph >= Ho + pad) ? 0.0f : top_diff[(pn * Ho + ph - pad) * Wo + pw - pad];
+    }
+}
 ORC_API void orc_sphere_cut_edge(const float *in, float *out, int NC, int H, int W, int pad) {
     int Ho = H - 2 * pad, Wo = W - 2 * pad;
     long total = (long)NC * Ho * Wo;
@@ -453,6 +514,63 @@ ORC_API void orc_imp_map_constrain(float *constrain, int N, int H, float rt, flo
             constrain[n * H + h] = rt * t;
         }
     free(a);
+}
+/* alpha_t of ImpMapOp (extension/imp_map_cuda.cu:27-36,49-52): alpha / (|cos| / max * sw + 1 - sw), fp32 steps as torch does them */
+ORC_API void orc_imp_map_alpha(float *alpha_t, int H, float alpha, float sw) {
+    float pi = (float)acos(-1.0), mx = 0.0f;
+    for (int h = 0; h < H; ++h) {
+        float v = (float)cos((double)(float)((0.5 - ((double)h + 0.5) / (double)H) * (double)pi));
+        alpha_t[h] = v < 0 ? -v : v;
+        if (alpha_t[h] > mx) mx = alpha_t[h];
+    }
+    for (int h = 0; h < H; ++h) {
+        float t = alpha_t[h] / mx;
+        t = t * sw;
+        t = t + 1.0f;
+        t = t - sw;
+        alpha_t[h] = alpha / t;
+    }
+}
+/* ImpMapOp.backward (extension/imp_map_cuda.cu:138-298): data_diff = top_diff under the importance mask (floor(imp*levels), no
+ * epsilon here), imp_diff by one of four rules (imp_kernel 0..3 -> kernels v1..v4), channel sums in ascending order.
+ * top_diff / data_diff [N][C][H][W]; imp, imp_diff [N][1][H][W]; sphere_constrain [N][H]; alpha_t [H] */
+ORC_API void orc_imp_map_backward(const float *top_diff, const float *imp, const float *sphere_constrain, const float *alpha_t,
+                                  float *data_diff, float *imp_diff, int N, int C, int H, int W, int levels, int imp_kernel, float gamma) {
+    const int cpl = C / levels;
+    const long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        long ps = i % inner, pc = (i / inner) % C, pn = i / inner / C;
+        int ch = (int)floor((double)(imp[pn * inner + ps] * (float)levels)) * cpl;
+        data_diff[i] = pc < ch ? top_diff[i] : 0.0f;
+    }
+    for (long index = 0; index < (long)N * inner; ++index) {
+        const long ps = index % inner, pn = index / inner;
+        const int ph = (int)(ps / W);
+        const float sc = sphere_constrain[index / W];
+        const int ch = (int)((double)(imp[index] * (float)levels) + 0.00001) * cpl;
+        if (imp_kernel == 3) {
+            const float decay = sc < 0 ? 0.1f : 1.0f;
+            long base = pn * C * inner + ps;
+            float tmp = 0.0f, tmax = -10000.0f;
+            int target = 0;
+            for (int i = 0; i < C; ++i) {
+                tmp = tmp + fabsf(top_diff[base]) - alpha_t[ph] * decay;
+                base += inner;
+                if (tmp > tmax) { tmax = tmp; target = i; }
+            }
+            imp_diff[index] = target < ch ? gamma : (target > ch ? -gamma : 0.0f);
+            continue;
+        }
+        const int c0 = imp_kernel == 2 ? 0 : ch;
+        long base = (pn * C + c0) * inner + ps;
+        float diff = 0.0f;
+        if (sc > 0) diff = imp_kernel == 0 ? alpha_t[ph] * (float)(C - ch) : alpha_t[ph];
+        for (int i = c0; i < C; ++i) {
+            diff -= fabsf(top_diff[base]);
+            base += inner;
+        }
+        imp_diff[index] = diff;
+    }
 }
 ORC_API void orc_imp2mask(const float *in, float *out, int N, int C, int H, int W, int cpn) {
     long inner = (long)H * W, total = (long)N * C * inner;

@@ -176,6 +176,9 @@ lib.orc_sphere_pad.argtypes = [_f, _f] + [C.c_int] * 4
 lib.orc_sphere_pad_inplace.argtypes = [_f] + [C.c_int] * 4
 lib.orc_sphere_trim.argtypes = [_f] + [C.c_int] * 4
 lib.orc_sphere_cut_edge.argtypes = [_f, _f] + [C.c_int] * 4
+lib.orc_sphere_pad_backward.argtypes = [_f, _f] + [C.c_int] * 4
+lib.orc_sphere_pad_backward_inplace.argtypes = [_f] + [C.c_int] * 4
+lib.orc_sphere_cut_edge_backward.argtypes = [_f, _f] + [C.c_int] * 4
 lib.orc_sphere_lat_scale.argtypes = [_f, _f, _f] + [C.c_int] * 4
 lib.orc_imp_map.argtypes = [_f, _f, _f, _PF] + [C.c_int] * 5
 lib.orc_imp_map_constrain.argtypes = [_f, C.c_int, C.c_int, C.c_float, C.c_float]
@@ -229,6 +232,26 @@ def sphere_cut_edge(x, pad):
     return out
 
 
+def sphere_pad_backward(top_diff, pad):
+    N, Cc, Ho, Wo = top_diff.shape
+    out = np.empty((N, Cc, Ho - 2 * pad, Wo - 2 * pad), np.float32)
+    lib.orc_sphere_pad_backward(out, f32(top_diff), N * Cc, Ho - 2 * pad, Wo - 2 * pad, pad)
+    return out
+
+
+def sphere_pad_backward_inplace(diff, pad):
+    N, Cc, Hp, Wp = diff.shape
+    lib.orc_sphere_pad_backward_inplace(diff, N * Cc, Hp, Wp, pad)
+    return diff
+
+
+def sphere_cut_edge_backward(top_diff, pad):
+    N, Cc, Ho, Wo = top_diff.shape
+    out = np.empty((N, Cc, Ho + 2 * pad, Wo + 2 * pad), np.float32)
+    lib.orc_sphere_cut_edge_backward(out, f32(top_diff), N * Cc, Ho + 2 * pad, Wo + 2 * pad, pad)
+    return out
+
+
 def sphere_lat_scale(x, weight, npart):
     N, Cc, H, W = x.shape
     out = np.empty_like(x, dtype=np.float32)
@@ -248,6 +271,23 @@ def imp_map_constrain(N, H, rt, sc):
     out = np.empty((N, 1, H), np.float32)
     lib.orc_imp_map_constrain(out.reshape(-1), N, H, rt, sc)
     return out
+
+
+lib.orc_imp_map_alpha.argtypes = [_f, C.c_int, C.c_float, C.c_float]
+lib.orc_imp_map_backward.argtypes = [_f, _f, _f, _f, _f, _f] + [C.c_int] * 6 + [C.c_float]
+
+
+def imp_map_alpha(H, alpha, sw):
+    out = np.empty(H, np.float32)
+    lib.orc_imp_map_alpha(out, H, alpha, sw)
+    return out
+
+
+def imp_map_backward(top_diff, imp, sphere_constrain, alpha_t, levels, imp_kernel, gamma):
+    N, Cc, H, W = top_diff.shape
+    dd, di = np.empty((N, Cc, H, W), np.float32), np.empty((N, 1, H, W), np.float32)
+    lib.orc_imp_map_backward(f32(top_diff), f32(imp), f32(sphere_constrain).reshape(-1), f32(alpha_t), dd, di, N, Cc, H, W, levels, imp_kernel, gamma)
+    return dd, di
 
 
 def imp2mask(x, levels, channels):

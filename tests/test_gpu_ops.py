@@ -344,6 +344,62 @@ def test_mask_constrain_and_maskconv2(lic, ngroup, c_in, c_out, k, hidden):
     assert np.array_equal(host(mc.weight), orc.mask_constrain(host(mc.weight), ngroup, constrain))
 
 
+def _sphere_pad_torch(x, pad):
+    """SpherePad written with torch indexing only (differentiable): wrap columns, mirror + half-turn shifted pole rows"""
+    W = x.shape[-1]
+    body = torch.cat([x[..., W - pad:], x, x[..., :pad]], -1)                # wrap in longitude
+    top = torch.flip(x[..., :pad, :], (-2,))                                # rows pad-1 .. 0, seen from across the pole:
+    bot = torch.flip(x[..., x.shape[-2] - pad:, :], (-2,))
+    def across(r):                                                          # column tw of the apron shows column W-1-tw, corners likewise
+        r = torch.flip(r, (-1,))
+        return torch.cat([r[..., W - pad:], r, r[..., :pad]], -1)
+    return torch.cat([across(top), body, across(bot)], -2)
+
+
+@pytest.mark.parametrize("N,C,H,W,pad", [(2, 3, 6, 10, 2), (1, 2, 4, 8, 1), (1, 1, 5, 7, 2)])
+def test_sphere_op_gradients(lic, N, C, H, W, pad):
+    """SpherePadOp.backward (both forms) and SphereCutEdgeOp.backward: bit-exact against the oracle, and equal to torch autograd
+    through an index-only formulation of the forward (which the forward itself is checked against first)"""
+    rng = np.random.default_rng(H * 10 + W)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    g = rng.standard_normal((N, C, H + 2 * pad, W + 2 * pad)).astype(np.float32)
+    op = lic.SpherePadOp(pad, False, 0, False)
+    assert np.array_equal(host(op.forward(dev(x))[0]), host(_sphere_pad_torch(dev(x), pad)))
+    got = host(op.backward(dev(g))[0])
+    assert np.array_equal(got, orc.sphere_pad_backward(g, pad))
+    xt = dev(x).requires_grad_(True)
+    _sphere_pad_torch(xt, pad).backward(dev(g))
+    assert torch.allclose(dev(got), xt.grad, rtol=1e-6, atol=1e-6)         # same terms, autograd's own summation order
+    gi = dev(g)
+    assert lic.SpherePadOp(pad, True, 0, False).backward(gi)[0] is gi and np.array_equal(host(gi), orc.sphere_pad_backward_inplace(g.copy(), pad))
+    assert np.array_equal(host(gi)[..., pad:-pad, pad:-pad], got)          # interior = the not-in-place gradient, apron untouched
+    ce = lic.SphereCutEdgeOp(pad, 0, False)
+    gc = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    want = np.pad(gc, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    ce.forward(dev(g))
+    assert np.array_equal(host(ce.backward(dev(gc))[0]), want) and np.array_equal(orc.sphere_cut_edge_backward(gc, pad), want)
+
+
+@pytest.mark.parametrize("imp_kernel", [0, 1, 2, 3])
+def test_imp_map_backward(lic, imp_kernel):
+    """ImpMapOp.backward: gradient of the data under the importance mask and the four importance-gradient rules (v1..v4), bit-exact vs
+    the oracle given the same alpha_t; alpha_t itself (a cosine per row) within 1e-6 like the constraint tensor"""
+    N, C, H, W, levels = 2, 24, 6, 10, 6
+    rng = np.random.default_rng(70 + imp_kernel)
+    g = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    imp = (np.floor(rng.random((N, 1, H, W)) * (levels + 1)) / levels).astype(np.float32)       # 0 .. 1 in steps of 1/levels
+    sc = rng.standard_normal((N, 1, H)).astype(np.float32)                                       # both signs
+    op = lic.ImpMapOp(levels, 0.13, 0.7, 0.5, 0.61, 0.61, imp_kernel, 1, 0, False)
+    dd, di = op.backward(dev(g), dev(imp), dev(sc))
+    alpha = host(op._alpha)
+    assert np.allclose(alpha, orc.imp_map_alpha(H, 0.13, 0.61), rtol=1e-6, atol=1e-6)
+    rd, ri = orc.imp_map_backward(g, imp, sc, alpha, levels, imp_kernel, np.float32(0.7))
+    assert np.array_equal(host(dd), rd) and np.array_equal(host(di), ri)
+    # the data gradient is the forward mask applied to the gradient wherever imp*levels is not within 1e-5 below an integer
+    fwd_mask = orc.imp_map(np.ones_like(g), imp, levels)[0]
+    assert np.array_equal(rd, g * fwd_mask)
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
