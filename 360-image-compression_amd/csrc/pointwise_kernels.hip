@@ -642,6 +642,84 @@ LIC360_API int lic360_quant(void *stream, const float *x, const float *weight_b,
     LAUNCH_CHECK();
     return 0;
 }
+// ---- QuantOp training side
+__global__ void k_quant_update_weight(float *__restrict__ weight, float *__restrict__ ncount, int C, int levels, float weight_decay) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    float *w = weight + (long)i * levels, *cnt = ncount + (long)i * levels;
+    int j = levels - 1;
+    for (; j > 1; j--)
+        if (cnt[j] >= 1e-3f) break;
+    float tmp = w[j] - lic360_logf((float)(levels - j));
+    for (; j < levels; j++) w[j] = tmp;
+    if (cnt[0] < 1e-3f) {
+        w[0] = w[0] + lic360_expf(w[1]);
+        tmp = lic360_logf((lic360_expf(w[1]) + lic360_expf(w[2])) / 2.0f);
+        w[1] = tmp;
+        w[2] = tmp;
+    }
+    for (j = 0; j < levels; ++j) cnt[j] = cnt[j] * weight_decay;
+}
+LIC360_API int lic360_quant_update_weight(void *stream, float *weight, float *ncount, int c, int levels, float weight_decay) {
+    ARG_CHECK(weight && ncount && c > 0 && levels >= 3);
+    hipLaunchKernelGGL(k_quant_update_weight, dim3(lic360_blocks(c)), dim3(256), 0, (hipStream_t)stream, weight, ncount, c, levels, weight_decay);
+    LAUNCH_CHECK();
+    return 0;
+}
+// workgroup (channel, level j): sum of (top - bottom) over the channel's elements with index >= j, in a fixed order (thread-strided
+// partial sums, then a tree over the workgroup): reproducible, unlike the reference's float atomics
+__global__ __launch_bounds__(256) void k_quant_weight_diff(const float *__restrict__ bottom, const float *__restrict__ top, const float *__restrict__ qidx,
+                                                           const float *__restrict__ wq, float *__restrict__ weight_diff, int N, int C, long inner, int levels) {
+    __shared__ float red[256];
+    const int pc = blockIdx.x / levels, j = blockIdx.x % levels;
+    float acc = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        const long base = ((long)n * C + pc) * inner;
+        for (long i = threadIdx.x; i < inner; i += 256)
+            if ((int)qidx[base + i] >= j) acc += top[base + i] - bottom[base + i];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) weight_diff[pc * levels + j] = j ? red[0] * wq[pc * levels + j] : red[0];
+}
+__global__ void k_quant_data_diff(const float *__restrict__ top_diff0, const float *__restrict__ top_diff1, const float *__restrict__ bottom,
+                                  const float *__restrict__ top, const float *__restrict__ qidx, const float *__restrict__ wq, float *__restrict__ data_diff,
+                                  long total, long inner, int C, int levels, float alpha) {
+    GRID_STRIDE(i, total) {
+        float g = top_diff0[i];
+        if (top_diff1) {
+            const int tc = (int)((i / inner) % C), q = (int)qidx[i];
+            const float *w = wq + tc * levels;
+            float beta;
+            if (top[i] < bottom[i]) beta = q < levels - 1 ? w[q + 1] : 10000.0f;
+            else if (top[i] > bottom[i]) beta = q > 0 ? w[q] : 10000.0f;
+            else if (q == 0) beta = w[q + 1];
+            else if (q < levels - 1) beta = (float)(((double)w[q] + (double)w[q + 1]) / 2.0);
+            else beta = w[q];
+            if (beta < 0.001f) beta = 0.001f;
+            g = g + alpha * top_diff1[i] / beta;
+        }
+        data_diff[i] = g;
+    }
+}
+LIC360_API int lic360_quant_backward(void *stream, const float *top_diff0, const float *top_diff1, const float *bottom_data, const float *top_data,
+                                     const float *qidx, const float *wq, float *data_diff, float *weight_diff, int n, int c, int h, int w, int levels,
+                                     float top_alpha) {
+    ARG_CHECK(top_diff0 && bottom_data && top_data && qidx && wq && data_diff && weight_diff && n > 0 && c > 0 && h > 0 && w > 0 && levels > 0 &&
+              (long)c * levels < (1l << 30));
+    const long inner = (long)h * w, total = (long)n * c * inner;
+    hipLaunchKernelGGL(k_quant_weight_diff, dim3((unsigned)(c * levels)), dim3(256), 0, (hipStream_t)stream, bottom_data, top_data, qidx, wq, weight_diff, n, c,
+                       inner, levels);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_quant_data_diff, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, top_diff0, top_diff1, bottom_data, top_data, qidx, wq,
+                       data_diff, total, inner, c, levels, top_alpha);
+    LAUNCH_CHECK();
+    return 0;
+}
 LIC360_API int lic360_dquant(void *stream, const float *x, const float *mask, const float *weight_b, float *wc, float *out,
                              int n, int c, int h, int w, int levels) {
     ARG_CHECK(x && mask && weight_b && wc && out && n > 0 && c > 0 && levels > 0);

@@ -70,6 +70,17 @@ int lic360_scale(void *stream, const float *x, float *out, long count, float bia
  *                                            extension/quant_cuda.cu:136-169 */
 int lic360_quant(void *stream, const float *x, const float *weight_b, float *wq_scratch, float *top, float *qidx, float *count,
                  int n, int c, int h, int w, int levels);
+/* QuantOp training side.  update_weight: trailing levels without samples share one increment, an empty first level moves the first
+ * centre, then the counts decay by weight_decay (in place on weight [c,levels] and ncount [c,levels])
+ *                                            extension/quant_cuda.cu:87-133 */
+int lic360_quant_update_weight(void *stream, float *weight, float *ncount, int c, int levels, float weight_decay);
+/* QuantOp.backward: weight_diff [c,levels] = per-channel sums of (top_data - bottom_data) over the elements with index >= j (times the
+ * level increment for j > 0; summed per workgroup in a fixed order, the reference uses float atomics), data_diff = top_diff0
+ * (+ top_alpha * top_diff1 / beta when top_diff1 != NULL); qidx = the indices of the forward pass as floats, wq = its level increments
+ *                                            extension/quant_cuda.cu:170-262 */
+int lic360_quant_backward(void *stream, const float *top_diff0, const float *top_diff1, const float *bottom_data, const float *top_data,
+                          const float *qidx, const float *wq, float *data_diff, float *weight_diff, int n, int c, int h, int w, int levels,
+                          float top_alpha);
 /* DquantOp.forward                           extension/dquant_cuda.cu:49-68 */
 int lic360_dquant(void *stream, const float *x, const float *mask, const float *weight_b, float *wc_scratch, float *out,
                   int n, int c, int h, int w, int levels);

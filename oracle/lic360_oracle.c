@@ -617,6 +617,64 @@ ORC_API void orc_quant(const float *in, const float *weight_b, float *top, float
     }
     free(wq);
 }
+/* QuantOp training side.
+ * update_weight (extension/quant_cuda.cu:87-133): per channel, the trailing levels that received (almost) no samples share one
+ * increment; an empty first level moves the first centre up; then the counts decay.  exp / log: lic360_exact_math.h (the reference
+ * uses libdevice: unpinned at the last ulp, like the tables) */
+ORC_API void orc_quant_update_weight(float *weight, float *ncount, int C, int levels, float weight_decay) {
+    for (int i = 0; i < C; ++i) {
+        int j = levels - 1;
+        for (; j > 1; j--)
+            if (ncount[i * levels + j] >= 1e-3f) break;
+        float tmp = weight[i * levels + j] - lic360_logf((float)(levels - j));
+        for (; j < levels; j++) weight[i * levels + j] = tmp;
+        if (ncount[i * levels] < 1e-3f) {
+            weight[i * levels] = weight[i * levels] + lic360_expf(weight[i * levels + 1]);
+            tmp = lic360_logf((lic360_expf(weight[i * levels + 1]) + lic360_expf(weight[i * levels + 2])) / 2.0f);
+            weight[i * levels + 1] = tmp;
+            weight[i * levels + 2] = tmp;
+        }
+    }
+    for (int i = 0; i < C * levels; ++i) ncount[i] = ncount[i] * weight_decay;
+}
+/* quant_backward (extension/quant_cuda.cu:135-262): weight_diff[c][j] = sum over the channel's elements with index >= j of
+ * (top_data - bottom_data), times the level increment for j > 0 (the reference accumulates with float atomics in no fixed order:
+ * here in double); data_diff = top_diff0 (straight through) + top_alpha * top_diff1 / beta when the index output has a gradient */
+ORC_API void orc_quant_backward(const float *top_diff0, const float *top_diff1, const float *bottom_data, const float *top_data,
+                                const float *qidx, const float *weight_b, float *data_diff, float *weight_diff,
+                                int N, int C, int H, int W, int levels, float top_alpha) {
+    float *wq = (float *)malloc(sizeof(float) * C * levels);
+    double *acc = (double *)calloc((size_t)C * levels, sizeof(double));
+    for (int i = 0; i < C * levels; ++i) wq[i] = (i % levels == 0) ? weight_b[i] : lic360_expf(weight_b[i]);
+    long inner = (long)H * W, total = (long)N * C * inner;
+    for (long i = 0; i < total; ++i) {
+        int pc = (int)((i / inner) % C), q = (int)qidx[i];
+        float d = top_data[i] - bottom_data[i];
+        for (int j = 0; j <= q; ++j) acc[pc * levels + j] += (double)d;
+    }
+    for (int i = 0; i < C * levels; ++i) {
+        float v = (float)acc[i];
+        weight_diff[i] = (i % levels != 0) ? v * wq[i] : v;
+    }
+    for (long i = 0; i < total; ++i) {
+        float g = top_diff0[i];
+        if (top_diff1) {
+            int tc = (int)((i / inner) % C), q = (int)qidx[i];
+            const float *w = wq + tc * levels;
+            float beta;
+            if (top_data[i] < bottom_data[i]) beta = q < levels - 1 ? w[q + 1] : 10000.0f;
+            else if (top_data[i] > bottom_data[i]) beta = q > 0 ? w[q] : 10000.0f;
+            else if (q == 0) beta = w[q + 1];
+            else if (q < levels - 1) beta = (float)(((double)w[q] + (double)w[q + 1]) / 2.0);
+            else beta = w[q];
+            if (beta < 0.001f) beta = 0.001f;
+            g = g + top_alpha * top_diff1[i] / beta;
+        }
+        data_diff[i] = g;
+    }
+    free(wq);
+    free(acc);
+}
 ORC_API void orc_dquant(const float *in, const float *mask, const float *weight_b, float *out,
                         int N, int C, int H, int W, int levels) {
     float *wc = (float *)malloc(sizeof(float) * C * levels);

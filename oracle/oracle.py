@@ -320,6 +320,24 @@ def quant(x, weight_b):
     return top, qidx, count
 
 
+lib.orc_quant_update_weight.argtypes = [_f, _f, C.c_int, C.c_int, C.c_float]
+lib.orc_quant_backward.argtypes = [_f, C.c_void_p, _f, _f, _f, _f, _f, _f] + [C.c_int] * 5 + [C.c_float]
+
+
+def quant_update_weight(weight_b, ncount, weight_decay):
+    w, c = np.ascontiguousarray(weight_b, np.float32).copy(), np.ascontiguousarray(ncount, np.float32).copy()
+    lib.orc_quant_update_weight(w, c, w.shape[0], w.shape[1], weight_decay)
+    return w, c
+
+
+def quant_backward(top_diff0, top_diff1, bottom_data, top_data, qidx, weight_b, top_alpha):
+    N, Cc, H, W = bottom_data.shape
+    dd, wd = np.empty((N, Cc, H, W), np.float32), np.empty(weight_b.shape, np.float32)
+    lib.orc_quant_backward(f32(top_diff0), _fp(None if top_diff1 is None else f32(top_diff1)), f32(bottom_data), f32(top_data), f32(qidx), f32(weight_b),
+                           dd, wd, N, Cc, H, W, weight_b.shape[1], top_alpha)
+    return dd, wd
+
+
 def dquant(x, mask, weight_b):
     N, Cc, H, W = x.shape
     out = np.empty((N, Cc, H, W), np.float32)

@@ -400,6 +400,41 @@ def test_imp_map_backward(lic, imp_kernel):
     assert np.array_equal(rd, g * fwd_mask)
 
 
+@pytest.mark.parametrize("ntop", [1, 2])
+def test_quant_training_path(lic, ntop):
+    """QuantOp with train=True: update_weight every check_iters calls (bit-exact vs the oracle: same exp / log), then backward --
+    data gradient bit-exact (straight through, plus the index-output term when ntop = 2), weight gradient within 1e-5 (the oracle
+    sums in double, the kernel per workgroup in a fixed tree; the reference itself uses float atomics in no fixed order)"""
+    N, C, H, W, L = 2, 6, 8, 12, 8
+    rng = np.random.default_rng(90 + ntop)
+    wb = np.concatenate([rng.uniform(-1, 0, (C, 1)), rng.uniform(-2, -0.5, (C, L - 1))], 1).astype(np.float32)
+    x = rng.uniform(-1.5, 2.5, (N, C, H, W)).astype(np.float32)
+    x[:, 0] = -5.0                                                          # channel 0: everything in level 0 -> trailing levels empty
+    x[:, 1] = 50.0                                                          # channel 1: everything in the last level -> first level empty
+    op = lic.QuantOp(C, L, 0.9, 2, ntop, 0.1, 0, False)
+    wd, cnt = dev(wb), dev(np.zeros((C, L), np.float32))
+    w_ref, c_ref = wb.copy(), np.zeros((C, L), np.float32)
+    for it in range(3):
+        if it == 2:                                                         # iter_ = 2: the update runs before this forward
+            w_ref, c_ref = orc.quant_update_weight(w_ref, c_ref, np.float32(0.9))
+        out = op.forward(dev(x), wd, cnt, True)
+        rt, rq, rc = orc.quant(x, w_ref)
+        assert np.array_equal(host(wd), w_ref) and np.array_equal(host(out[0]), rt) and np.array_equal(host(op.count_data_), rc), it
+        cnt += op.count_data_ * 0 + dev(rc) * np.float32(-0.001)            # what an optimiser step on `count` does (grad = count_data_)
+        c_ref = c_ref + rc * np.float32(-0.001)
+        assert np.allclose(host(cnt), c_ref, rtol=0, atol=1e-7)
+        c_ref = host(cnt)
+    assert not np.array_equal(w_ref, wb)                                    # the update did change the two degenerate channels
+    g0 = rng.standard_normal(x.shape).astype(np.float32)
+    g1 = rng.standard_normal(x.shape).astype(np.float32)
+    tops = [dev(g0), dev(g1)] if ntop == 2 else [dev(g0)]
+    dd, wdif, cd = op.backward(tops, dev(x), out[0])
+    rd, rw = orc.quant_backward(g0, g1 if ntop == 2 else None, x, rt, rq, w_ref, np.float32(0.1))
+    assert np.array_equal(host(dd), rd)
+    assert np.allclose(host(wdif), rw, rtol=1e-5, atol=1e-4 * float(np.abs(rw).max()))
+    assert cd is op.count_data_
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
