@@ -435,6 +435,45 @@ def test_quant_training_path(lic, ntop):
     assert cd is op.count_data_
 
 
+def test_linear_ops_backward_is_the_adjoint(lic):
+    """every linear drop-in op with a backward: <forward(x), g> == <x, backward(g)> for random x, g (the defining property of a
+    gradient of a linear map) -- pad / trim / cut-edge, pixel shuffle both ways, latitude scaling, context reshape / shift, and the
+    data path of ImpMap"""
+    rng = np.random.default_rng(77)
+    rnd = lambda *s: dev(rng.standard_normal(s).astype(np.float32))
+
+    def adjoint(fwd, bwd, x, gshape):
+        y = fwd(x)
+        g = rnd(*gshape) if gshape else rnd(*y.shape)
+        lhs = float((y.double() * g.double()).sum())
+        gx = bwd(g)
+        rhs = float((x.double() * gx.double()).sum())
+        assert abs(lhs - rhs) <= 1e-4 * (abs(lhs) + 1.0), (lhs, rhs)
+
+    x = rnd(2, 8, 6, 10)
+    p = lic.SpherePadOp(2, False, 0, False)
+    adjoint(lambda t: p.forward(t)[0].clone(), lambda g: p.backward(g)[0], x, None)
+    tr = lic.SphereTrimOp(2, 0, False)
+    adjoint(lambda t: tr.forward(t.clone())[0], lambda g: tr.backward(g.clone())[0], rnd(2, 8, 10, 14), None)
+    ce = lic.SphereCutEdgeOp(1, 0, False)
+    adjoint(lambda t: ce.forward(t)[0].clone(), lambda g: ce.backward(g)[0], x, None)
+    for d2w, shape in ((True, (2, 8, 6, 10)), (False, (2, 2, 6, 10))):
+        dt = lic.DtowOp(2, d2w, 0, False)
+        adjoint(lambda t: dt.forward(t)[0].clone(), lambda g: dt.backward(g)[0], rnd(*shape), None)
+    ls = lic.SphereLatScaleOp(3, 0, False)
+    wl = rnd(3)
+    adjoint(lambda t: ls.forward(t, wl)[0].clone(), lambda g: ls.backward(g, wl)[0], x, None)
+    cr = lic.ContextReshapeOp(4, 0, False)
+    adjoint(lambda t: cr.forward(t)[0].clone(), lambda g: cr.backward(g)[0], x, None)
+    sh = lic.ContexShiftOp(False, 2, 0, False)
+    adjoint(lambda t: sh.forward(t)[0].clone(), lambda g: sh.backward(g)[0], x, None)
+    levels = 4
+    im = lic.ImpMapOp(levels, 0.1, 1.0, 0.5, 0.61, 0.61, 0, 1, 0, False)
+    imp = dev((np.floor(rng.random((2, 1, 6, 10)) * (levels + 1)) / levels).astype(np.float32))
+    sc = dev(np.ones((2, 1, 6), np.float32))
+    adjoint(lambda t: im.forward(t, imp)[0].clone(), lambda g: im.backward(g, imp, sc)[0], x, None)
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
