@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import lic360
 from .base import BaseOpModule, contiguous
+from .autograd import UnaryFn, ImpMapFn, QuantFn, recording
 
 
 class ImpMap(BaseOpModule):
@@ -16,14 +17,16 @@ class ImpMap(BaseOpModule):
         self.level = levels
         self.ntop = ntop
 
-    @torch.no_grad()
     def forward(self, x, imp):
-        imp = (torch.floor(imp * self.level) / self.level).contiguous()      # IMP_MAP_AF2.forward, ImpMap.py:39
-        out = self._op(x).forward(contiguous(x), imp)
-        rt = torch.mean(imp)
-        if self.ntop > 1:
-            return out[0], out[2], rt
-        return out[0], rt
+        if recording(x, imp):
+            return ImpMapFn.apply(contiguous(x), imp, self.level, self._op(x), self.ntop > 1)
+        with torch.no_grad():
+            imp = (torch.floor(imp * self.level) / self.level).contiguous()  # the map takes `levels` + 1 values (ImpMap.py:39)
+            out = self._op(x).forward(contiguous(x), imp)
+            rt = torch.mean(imp)
+            if self.ntop > 1:
+                return out[0], out[2], rt
+            return out[0], rt
 
 
 class QUANT(BaseOpModule):
@@ -36,10 +39,12 @@ class QUANT(BaseOpModule):
         self.count = nn.Parameter(torch.zeros((channel, bin_num), dtype=torch.float32))
         self.op = {gid: lic360.QuantOp(channel, bin_num, weight_decay, check_iters, ntop, top_alpha, gid, time_flag) for gid in self.device_list}
 
-    @torch.no_grad()
     def forward(self, x):
-        out = self._op(x).forward(contiguous(x), self.weight, self.count, False)
-        return out[0] if len(out) == 1 else (out[0], out[1])
+        if recording(x, self.weight):
+            return QuantFn.apply(contiguous(x), self.weight, self.count, self._op(x), self.training)
+        with torch.no_grad():
+            out = self._op(x).forward(contiguous(x), self.weight, self.count, self.training)
+            return out[0] if len(out) == 1 else (out[0], out[1])
 
 
 class Dquant(BaseOpModule):
@@ -58,9 +63,11 @@ class Dtow(BaseOpModule):
         super().__init__(device)
         self.op = {gid: lic360.DtowOp(stride, d2w, gid, time_it) for gid in self.device_list}
 
-    @torch.no_grad()
     def forward(self, x):
-        return self._op(x).forward(contiguous(x))[0]
+        if recording(x):
+            return UnaryFn.apply(contiguous(x), self._op(x), False)
+        with torch.no_grad():
+            return self._op(x).forward(contiguous(x))[0]
 
 
 class Imp2mask(BaseOpModule):
@@ -88,9 +95,11 @@ class ContextReshape(BaseOpModule):
         super().__init__(device)
         self.op = {gid: lic360.ContextReshapeOp(ngroup, gid, time_it) for gid in self.device_list}
 
-    @torch.no_grad()
     def forward(self, x):
-        return self._op(x).forward(contiguous(x))[0]
+        if recording(x):
+            return UnaryFn.apply(contiguous(x), self._op(x), False)
+        with torch.no_grad():
+            return self._op(x).forward(contiguous(x))[0]
 
 
 class ContextShift(BaseOpModule):
@@ -98,6 +107,8 @@ class ContextShift(BaseOpModule):
         super().__init__(device)
         self.op = {gid: lic360.ContexShiftOp(inv, cpn, gid, time_it) for gid in self.device_list}
 
-    @torch.no_grad()
     def forward(self, x):
-        return self._op(x).forward(contiguous(x))[0]
+        if recording(x):
+            return UnaryFn.apply(contiguous(x), self._op(x), False)
+        with torch.no_grad():
+            return self._op(x).forward(contiguous(x))[0]

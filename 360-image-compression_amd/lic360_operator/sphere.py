@@ -6,16 +6,20 @@ import torch
 import torch.nn as nn
 import lic360
 from .base import BaseOpModule, contiguous
+from .autograd import UnaryFn, LatScaleFn, recording
 
 
 class SpherePad(BaseOpModule):
     def __init__(self, pad, device=0, inplace=False, time_it=False):
         super().__init__(device)
         self.op = {gid: lic360.SpherePadOp(pad, inplace, gid, time_it) for gid in self.device_list}
+        self.inplace = bool(inplace)
 
-    @torch.no_grad()
     def forward(self, x):
-        return self._op(x).forward(x if x.is_contiguous() else x.contiguous())[0]
+        if recording(x):
+            return UnaryFn.apply(contiguous(x), self._op(x), self.inplace)
+        with torch.no_grad():
+            return self._op(x).forward(contiguous(x))[0]
 
 
 class SphereTrim(BaseOpModule):
@@ -23,9 +27,11 @@ class SphereTrim(BaseOpModule):
         super().__init__(device)
         self.op = {gid: lic360.SphereTrimOp(pad, gid, time_it) for gid in self.device_list}
 
-    @torch.no_grad()
     def forward(self, x):
-        return self._op(x).forward(x)[0]
+        if recording(x):
+            return UnaryFn.apply(x, self._op(x), True)
+        with torch.no_grad():
+            return self._op(x).forward(x)[0]
 
 
 class SphereCutEdge(BaseOpModule):
@@ -33,9 +39,11 @@ class SphereCutEdge(BaseOpModule):
         super().__init__(device)
         self.op = {gid: lic360.SphereCutEdgeOp(pad, gid, time_it) for gid in self.device_list}
 
-    @torch.no_grad()
     def forward(self, x):
-        return self._op(x).forward(contiguous(x))[0]
+        if recording(x):
+            return UnaryFn.apply(contiguous(x), self._op(x), False)
+        with torch.no_grad():
+            return self._op(x).forward(contiguous(x))[0]
 
 
 class _ScaleResidualBlock(nn.Module):
@@ -65,7 +73,10 @@ class SphereLatScaleNet(BaseOpModule):
         ct = ct / np.max(ct)
         self.data = nn.Parameter(torch.from_numpy(ct).type(torch.float32).view(1, 1, npart), requires_grad=False)
 
-    @torch.no_grad()
     def forward(self, x):
-        weight = self.net(self.data.data).contiguous()
-        return self._op(x).forward(contiguous(x), weight)[0]
+        if recording(x, *self.net.parameters()):
+            weight = self.net(self.data.data).contiguous()
+            return LatScaleFn.apply(contiguous(x), weight, self._op(x))
+        with torch.no_grad():
+            weight = self.net(self.data.data).contiguous()
+            return self._op(x).forward(contiguous(x), weight)[0]

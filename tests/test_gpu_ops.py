@@ -474,6 +474,66 @@ def test_linear_ops_backward_is_the_adjoint(lic):
     adjoint(lambda t: im.forward(t, imp)[0].clone(), lambda g: im.backward(g, imp, sc)[0], x, None)
 
 
+def test_operator_modules_record_gradients(lic):
+    """the nn.Module wrappers of lic360_operator take part in autograd: gradients through them equal those through plain-torch
+    formulations of the same maps (pad, cut edge, trim, pixel shuffle, context reshape, latitude scaling), the quantiser is straight
+    through with the op's weight / count gradients, the importance map masks the data gradient"""
+    import lic360_operator as lo
+    import torch.nn.functional as F
+    rng = np.random.default_rng(123)
+    rnd = lambda *s: dev(rng.standard_normal(s).astype(np.float32))
+
+    def grads(fn, x, g):
+        x = x.clone().requires_grad_(True)
+        y = fn(x)
+        y.backward(g)
+        return y.detach().clone(), x.grad.clone()
+
+    x = rnd(2, 8, 6, 10)
+    for mod, ref in ((lo.SpherePad(2, 0), lambda t: _sphere_pad_torch(t, 2)),
+                     (lo.SphereCutEdge(1, 0), lambda t: t[..., 1:-1, 1:-1]),
+                     (lo.Dtow(2, True, 0), lambda t: F.pixel_shuffle(t, 2)),
+                     (lo.ContextReshape(4, 0), lambda t: t.reshape(2, 4, 2, 6, 10).permute(0, 1, 3, 4, 2).reshape(-1, 2))):
+        y_ref = ref(x)
+        g = rnd(*y_ref.shape)
+        (y1, g1), (y2, g2) = grads(mod, x, g), grads(ref, x, g)
+        assert torch.equal(y1, y2) and torch.allclose(g1, g2, rtol=1e-6, atol=1e-6), type(mod).__name__
+    # in-place trim on an activation (x * 1 is a non-leaf)
+    tr = lo.SphereTrim(2, 0)
+    keep = torch.zeros(6, 10, device="cuda:0")
+    keep[2:-2, 2:-2] = 1
+    g = rnd(2, 8, 6, 10)
+    (y1, g1), (y2, g2) = grads(lambda t: tr(t * 1.0), x, g), grads(lambda t: t * keep, x, g)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    # latitude scaling: gradients reach x and the little 1-D net
+    ls = lo.SphereLatScaleNet(3, 0).to("cuda:0")
+    xs = x.clone().requires_grad_(True)
+    ls(xs).backward(g)
+    got = [p.grad.clone() for p in ls.net.parameters()]
+    ls.zero_grad()
+    xr = x.clone().requires_grad_(True)
+    wrow = ls.net(ls.data.data).view(3).repeat_interleave(2)                # 6 rows, 3 bands
+    (xr * wrow.view(1, 1, 6, 1)).backward(g)
+    assert torch.allclose(xs.grad, xr.grad, rtol=1e-6, atol=1e-6)
+    for a, p in zip(got, ls.net.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-4, atol=1e-5)
+    # quantiser, train mode
+    q = lo.QUANT(8, 8, ntop=1, device_id=0).to("cuda:0").train()
+    xq = (x * 0.3 + 0.4).clone().requires_grad_(True)
+    yq = q(xq)
+    yq.backward(g)
+    assert torch.equal(xq.grad, g) and q.weight.grad.shape == q.weight.shape and bool(torch.isfinite(q.weight.grad).all())
+    assert torch.equal(q.count.grad, q.op[0].count_data_) and float(q.count.grad.sum()) == -float(x.numel())
+    # importance map
+    im = lo.ImpMap(0.5, 0.1, 1.0, 4, device=0)
+    imp = dev(rng.random((2, 1, 6, 10)).astype(np.float32)).requires_grad_(True)
+    xi = x.clone().requires_grad_(True)
+    out, rt = im(xi, imp)
+    out.backward(g)
+    mask = (out.detach() != 0) | (xi.detach() == 0)
+    assert torch.equal(xi.grad, g * mask) and imp.grad.shape == imp.shape and bool(torch.isfinite(imp.grad).all())
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
