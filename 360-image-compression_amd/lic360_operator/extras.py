@@ -8,7 +8,7 @@ metric / bookkeeping utilities, and two wrappers of out-of-scope native ops) and
   SSIM           11x11 Gaussian-window SSIM (lic360_operator/pytorch_ssim.py:16-63)
   ModuleSaver    best / latest checkpoint writer (lic360_operator/ModuleSaver.py:4-35)
   Logger         screen + file log (lic360_operator/Logger.py:3-23)
-  MultiProject   needs lic360.ProjectsOp  (viewport metrics)  -> raises on construction
+  MultiProject   the 14 viewports of lic360.ProjectsOp (viewport metrics)
   MaskConv2      torch conv2d over a weight masked by lic360.MaskConstrainOp (the training-time form of the context conv)
 """
 import math
@@ -157,10 +157,28 @@ class Logger(object):
 
 
 class MultiProject(nn.Module):
+    """14 viewports of every ERP image of a batch -- four around the equator, four each at +-45 degrees, the two poles -- for the
+    viewport metrics (reference lic360_operator/MultiProject.py:24-35; used as `MultiProject(171, 256, 0.5, False, gpu)` by
+    test/lic360_demo.py:424-425).  Output [n*14, c, h, w], viewport-major."""
+    THETAS = (-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0)
+    PHIS = (0, 0, 0, 0, 0.25, 0.25, 0.25, 0.25, -0.25, -0.25, -0.25, -0.25, 0.5, -0.5)
+
     def __init__(self, h, w, fov=0.6, near=False, device_id=0, time_flag=False):
         super().__init__()
-        raise NotImplementedError("MultiProject wraps lic360.ProjectsOp (14-viewport projection for VPSNR/VSSIM, "
-                                  "extension/projects_cuda.cu): viewport metrics are outside the accelerated path (SURVEY.md §8f.3)")
+        import lic360
+        from .autograd import UnaryFn, recording
+        self._fn, self._recording = UnaryFn, recording
+        self.thetas, self.phis = list(self.THETAS), list(self.PHIS)
+        devs = [device_id] if isinstance(device_id, int) else list(device_id)
+        self.op = {gid: lic360.ProjectsOp(int(h), int(w), self.thetas, self.phis, fov, near, gid, time_flag) for gid in devs}
+
+    def forward(self, x):
+        x = x if x.is_contiguous() else x.contiguous()
+        op = self.op[x.device.index]
+        if self._recording(x):
+            return self._fn.apply(x, op, False)
+        with torch.no_grad():
+            return op.forward(x)[0]
 
 
 class _MaskConstrainFn(torch.autograd.Function):

@@ -270,6 +270,20 @@ int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int layer, const
 int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const float *levels, int B, uint8_t *bytes, long cap, int *nbytes, int *err);
 int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B, float *levels_out, int *err);
 
+/* ---- f3 viewport projection (ProjectsOp, the sampling stage of VPSNR / VSSIM) -------------------------------------------------
+ * Sampling coordinates tf [14][h_out*w_out][2] = (x, y) in ERP pixels of the 14 rectilinear viewports (yaw theta*pi, pitch phi*pi, field
+ * of view fov*pi) on an ERP of height x width; host computes in fp32, device write
+ *                                            extension/projects.hpp:8-20, projects_cuda.cu:7-67,101-153 */
+int lic360_projects_tf(void *stream, float *tf_dev, int h_out, int w_out, const float *theta14, const float *phi14, float fov,
+                       int height, int width);
+/* ProjectsOp.forward: x [nc][h][w] -> out [14][nc][h_out][w_out] (viewport-major), bilinear or nearest
+ *                                            extension/projects_cuda.cu:181-232 */
+int lic360_projects_forward(void *stream, const float *x, const float *tf, float *out, int nc, int h, int w, int h_out, int w_out, int nearest);
+/* ProjectsOp.backward: scatter-add of the viewport gradients (in_diff) and of their interpolation weights (count), both [nc][h][w]
+ *                                            extension/projects_cuda.cu:234-329 */
+int lic360_projects_backward(void *stream, const float *top_diff, const float *tf, float *in_diff, float *count, int nc, int h, int w,
+                             int h_out, int w_out, int nearest);
+
 /* Test hooks of the DEVICE arithmetic coder (A19/A20 as they run inside the fused codec): raw int32 tables [n][ncode+1]
  * (every table totals 65536), labels and an optional mask, all in device memory, through the same kernels the codec
  * launches -- encode: k_ac_encode; decode: k_dec_init + k_dec_plane (ncode == 8) or k_imp_dec_plane (other alphabets),

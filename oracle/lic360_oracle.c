@@ -830,3 +830,104 @@ ORC_API void orc_ac_decode_slice(orc_ac *a, const int *table, int ncode, const f
         out[i] = (float)sym;
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * f3 viewport projection (ProjectsOp): 14 rectilinear viewports sampled from an ERP image.
+ * Set-up: extension/projects.hpp:8-20, projects_cuda.cu:7-18 (view rays), :20-49 (Rodrigues), :50-67 (rays -> ERP coordinates),
+ * :101-153 (init / update).  Everything in fp32 as the reference; sin / cos / asin / atan / sqrt are libm's here, libdevice's
+ * there (unpinned at the last ulp, like the tables' exp / erf).  tf [14][h_out*w_out][2] = (x, y) in ERP pixels.
+ * ---------------------------------------------------------------------------------- */
+static void orc_mrod(const float *x, const float *y, const float *z, float *data) {
+    for (int i = 0; i < 14; i++) {
+        float *d = data + i * 9;
+        for (int k = 0; k < 9; ++k) d[k] = 0.0f;
+        float norm = sqrtf(x[i] * x[i] + y[i] * y[i] + z[i] * z[i]);
+        if (norm == 0) { d[0] = 1.0f; d[4] = 1.0f; d[8] = 1.0f; continue; }
+        float tx = x[i] / norm, ty = y[i] / norm, tz = z[i] / norm, c = cosf(norm), sn = sinf(norm);
+        d[0] = c + (1 - c) * tx * tx;  d[1] = (1 - c) * tx * ty - sn * tz;  d[2] = (1 - c) * tx * tz + sn * ty;
+        d[3] = (1 - c) * ty * tx + sn * tz;  d[4] = c + (1 - c) * ty * ty;  d[5] = (1 - c) * ty * tz - sn * tx;
+        d[6] = (1 - c) * tz * tx - sn * ty;  d[7] = (1 - c) * tz * ty + sn * tx;  d[8] = c + (1 - c) * tz * tz;
+    }
+}
+ORC_API void orc_projects_tf(float *tf, int h_out, int w_out, const float *theta, const float *phi, float fov, int height, int width) {
+    const float pi = (float)acos(-1.0);
+    float th[14], ph[14], xa[14], ya[14], za[14], r1[126], r2[126], r[126];
+    for (int i = 0; i < 14; ++i) { th[i] = theta[i] * pi; ph[i] = phi[i] * pi; }
+    const float fovr = fov * pi;
+    const float hfov = fovr * h_out / w_out / 2, wfov = fovr / 2;
+    const float c_x = (float)((w_out - 1) / 2.0), c_y = (float)((h_out - 1) / 2.0);
+    const float pi_2 = pi / 2, wangle = pi_2 - wfov, hangle = pi_2 - hfov;
+    const float w_stride = 2 * sinf(wfov) / sinf(wangle) / (w_out - 1), h_stride = 2 * sinf(hfov) / sinf(hangle) / (h_out - 1);
+    for (int i = 0; i < 14; ++i) { xa[i] = 0; ya[i] = 0; za[i] = th[i]; }
+    orc_mrod(xa, ya, za, r1);
+    for (int i = 0; i < 14; ++i) { xa[i] = r1[i * 9 + 1] * (-ph[i]); ya[i] = r1[i * 9 + 4] * (-ph[i]); za[i] = r1[i * 9 + 7] * (-ph[i]); }
+    orc_mrod(xa, ya, za, r2);
+    for (int b = 0; b < 14; ++b)
+        for (int m = 0; m < 3; ++m)
+            for (int n = 0; n < 3; ++n) {
+                float sum = 0;
+                for (int j = 0; j < 3; ++j) sum += r2[b * 9 + m * 3 + j] * r1[b * 9 + j * 3 + n];
+                r[b * 9 + m * 3 + n] = sum;
+            }
+    const float hx = (float)((width - 1) / 2.0), hy = (float)((height - 1) / 2.0);
+    const int inner = h_out * w_out;
+    for (int b = 0; b < 14; ++b)
+        for (int i = 0; i < inner; ++i) {
+            const int w = i % w_out, h = i / w_out;
+            float x = 1.0f, y = (w - c_x) * w_stride, z = (h - c_y) * h_stride;
+            float rr = sqrtf(x * x + y * y + z * z);
+            float xa_ = x / rr, xb = y / rr, xc = -z / rr;
+            const float *m = r + b * 9;
+            float vx = xa_ * m[0] + xb * m[1] + xc * m[2], vy = xa_ * m[3] + xb * m[4] + xc * m[5], vz = xa_ * m[6] + xb * m[7] + xc * m[8];
+            float lat = asinf(vz), t = atanf(vy / vx);
+            if (vx <= 0) t = vy > 0 ? t + pi : t - pi;
+            tf[((long)b * inner + i) * 2] = t / pi * hx + hx;
+            tf[((long)b * inner + i) * 2 + 1] = -2 * lat / pi * hy + hy;
+        }
+}
+/* ProjectsOp.forward: out [14][NC][h_out*w_out] (extension/projects_cuda.cu:181-213) */
+ORC_API void orc_projects_forward(const float *in, const float *tf, float *out, int NC, int hs, int ws, int inner, int nearest) {
+    for (long index = 0; index < (long)14 * NC * inner; ++index) {
+        const int ps = (int)(index % inner), tn = (int)((index / inner) % NC), tb = (int)(index / inner / NC);
+        const float fx = tf[((long)tb * inner + ps) * 2], fy = tf[((long)tb * inner + ps) * 2 + 1];
+        const float *img = in + (long)tn * hs * ws;
+        if (nearest) {
+            int tw = (int)floor((double)fx + 0.5) % ws, th = (int)floor((double)fy + 0.5);
+            th = th >= hs ? hs - 1 : th;
+            out[index] = img[th * ws + tw];
+        } else {
+            int tw = (int)floorf(fx), th = (int)floorf(fy);
+            int pw = (tw + 1) % ws, ph = th + 1 >= hs ? hs - 1 : th + 1;
+            float tx = fx - tw, ty = fy - th, ntx = (float)(1. - tx), nty = (float)(1. - ty);
+            out[index] = img[th * ws + tw] * ntx * nty + img[th * ws + pw] * tx * nty + img[ph * ws + tw] * ntx * ty + img[ph * ws + pw] * tx * ty;
+        }
+    }
+}
+/* ProjectsOp.backward: scatter of the viewport gradients and of their weights (extension/projects_cuda.cu:234-299); double accumulators
+ * (the reference: float atomics in no fixed order) */
+ORC_API void orc_projects_backward(const float *top_diff, const float *tf, float *in_diff, float *count, int NC, int hs, int ws, int inner, int nearest) {
+    const long n_in = (long)NC * hs * ws;
+    double *acc = (double *)calloc((size_t)n_in, sizeof(double)), *cnt = (double *)calloc((size_t)n_in, sizeof(double));
+    for (long index = 0; index < (long)14 * NC * inner; ++index) {
+        const int ps = (int)(index % inner), tn = (int)((index / inner) % NC), tb = (int)(index / inner / NC);
+        const float fx = tf[((long)tb * inner + ps) * 2], fy = tf[((long)tb * inner + ps) * 2 + 1], g = top_diff[index];
+        const long base = (long)tn * hs * ws;
+        if (nearest) {
+            int tw = (int)floor((double)fx + 0.5) % ws, th = (int)floor((double)fy + 0.5);
+            th = th >= hs ? hs - 1 : th;
+            acc[base + th * ws + tw] += g;
+            cnt[base + th * ws + tw] += 1.0;
+        } else {
+            int tw = (int)floorf(fx), th = (int)floorf(fy);
+            int pw = (tw + 1) % ws, ph = th + 1 >= hs ? hs - 1 : th + 1;
+            float tx = fx - tw, ty = fy - th, ntx = (float)(1. - tx), nty = (float)(1. - ty);
+            acc[base + th * ws + tw] += (double)(ntx * nty * g);  cnt[base + th * ws + tw] += (double)(ntx * nty);
+            acc[base + th * ws + pw] += (double)(tx * nty * g);   cnt[base + th * ws + pw] += (double)(tx * nty);
+            acc[base + ph * ws + tw] += (double)(ntx * ty * g);   cnt[base + ph * ws + tw] += (double)(ntx * ty);
+            acc[base + ph * ws + pw] += (double)(tx * ty * g);    cnt[base + ph * ws + pw] += (double)(tx * ty);
+        }
+    }
+    for (long i = 0; i < n_in; ++i) { in_diff[i] = (float)acc[i]; count[i] = (float)cnt[i]; }
+    free(acc);
+    free(cnt);
+}

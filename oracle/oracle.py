@@ -450,3 +450,29 @@ def ref_decode(data, tables, ncode, mask, num, file_value=3.5):
     if rc:
         raise RuntimeError("reference decoder failed (%d)" % rc)
     return out
+
+
+# ---------------------------------------------------------------- f3 viewport projection
+lib.orc_projects_tf.argtypes = [_f, C.c_int, C.c_int, _f, _f, C.c_float, C.c_int, C.c_int]
+lib.orc_projects_forward.argtypes = [_f, _f, _f] + [C.c_int] * 5
+lib.orc_projects_backward.argtypes = [_f, _f, _f, _f] + [C.c_int] * 5
+
+
+def projects_tf(h_out, w_out, theta, phi, fov, height, width):
+    tf = np.empty((14, h_out * w_out, 2), np.float32)
+    lib.orc_projects_tf(tf, h_out, w_out, f32(theta), f32(phi), fov, height, width)
+    return tf
+
+
+def projects_forward(x, tf, h_out, w_out, nearest=False):
+    N, Cc, H, W = x.shape
+    out = np.empty((14 * N, Cc, h_out, w_out), np.float32)
+    lib.orc_projects_forward(f32(x), f32(tf), out, N * Cc, H, W, h_out * w_out, int(nearest))
+    return out
+
+
+def projects_backward(g, tf, N, Cc, H, W, nearest=False):
+    inner = g.shape[-1] * g.shape[-2]
+    d, c = np.empty((N, Cc, H, W), np.float32), np.empty((N, Cc, H, W), np.float32)
+    lib.orc_projects_backward(f32(g), f32(tf), d, c, N * Cc, H, W, inner, int(nearest))
+    return d, c

@@ -534,6 +534,75 @@ def test_operator_modules_record_gradients(lic):
     assert torch.equal(xi.grad, g * mask) and imp.grad.shape == imp.shape and bool(torch.isfinite(imp.grad).all())
 
 
+def _viewport_coords_float64(h_out, w_out, theta, phi, fov, H, W):
+    """the geometry of ProjectsOp in float64 with numpy only: pinhole rays (x = 1 forward, y right, z up) -> yaw about z by theta*pi, then
+    pitch by -phi*pi about the yawed y axis -> longitude / latitude -> ERP pixel coordinates"""
+    pi = np.pi
+    wf, hf = fov * pi / 2, fov * pi * h_out / w_out / 2
+    ys = (np.arange(w_out) - (w_out - 1) / 2) * (2 * np.tan(wf) / (w_out - 1))
+    zs = (np.arange(h_out) - (h_out - 1) / 2) * (2 * np.tan(hf) / (h_out - 1))
+    yy, zz = np.meshgrid(ys, zs)
+    rays = np.stack([np.ones_like(yy), yy, -zz], -1)
+    rays /= np.linalg.norm(rays, axis=-1, keepdims=True)
+
+    def rot(axis, ang):
+        a = np.asarray(axis, np.float64)
+        n = np.linalg.norm(a)
+        if n == 0 or ang == 0:
+            return np.eye(3)
+        k = a / n
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    out = np.empty((14, h_out * w_out, 2))
+    for v in range(14):
+        yaw = rot([0, 0, 1], theta[v] * pi)
+        R = rot(yaw[:, 1], -phi[v] * pi) @ yaw
+        d = rays.reshape(-1, 3) @ R.T
+        lon, lat = np.arctan2(d[:, 1], d[:, 0]), np.arcsin(np.clip(d[:, 2], -1, 1))
+        out[v, :, 0] = lon / pi * (W - 1) / 2 + (W - 1) / 2
+        out[v, :, 1] = -2 * lat / pi * (H - 1) / 2 + (H - 1) / 2
+    return out
+
+
+@pytest.mark.parametrize("near", [False, True])
+def test_projects_op_viewports(lic, near):
+    """ProjectsOp / MultiProject: sampling coordinates == oracle (both fp32 on the host) and == a float64 numpy statement of the geometry
+    to 1e-3 pixel (away from the +-pi seam); forward bit-exact vs the oracle; backward (float atomics) within 1e-5; <F x, g> = <x, F^T g>"""
+    import lic360_operator as lo
+    N, Cc, H, W, ho, wo, fov = 2, 3, 32, 64, 9, 13, 0.5
+    rng = np.random.default_rng(5)
+    th, ph = list(lo.MultiProject.THETAS), list(lo.MultiProject.PHIS)
+    op = lic.ProjectsOp(ho, wo, th, ph, fov, near, 0, False)
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    y = host(op.forward(dev(x))[0])
+    tf = host(op._tf)
+    tf_ref = orc.projects_tf(ho, wo, np.array(th, np.float32), np.array(ph, np.float32), np.float32(fov), H, W)
+    assert np.allclose(tf, tf_ref, rtol=0, atol=2e-4)
+    t64 = _viewport_coords_float64(ho, wo, th, ph, fov, H, W)
+    seam = np.abs(np.abs(t64[..., 0] - (W - 1) / 2) - (W - 1) / 2) < 0.05                   # lon = +-pi: either end of the row is right
+    lat = (0.5 - t64[..., 1] / (H - 1)) * np.pi
+    polar = np.cos(lat) < 0.05                                                              # longitude is ill-conditioned next to a pole
+    assert np.abs(tf - t64)[..., 1].max() < 1e-3 and np.abs(tf - t64)[..., 0][~seam & ~polar].max() < 1e-3
+    assert tf[..., 0].min() >= 0 and tf[..., 0].max() <= W - 1 and tf[..., 1].min() >= 0 and tf[..., 1].max() <= H - 1
+    assert abs(tf[1, (ho // 2) * wo + wo // 2, 0] - (W - 1) / 2) < 1e-3 and abs(tf[1, (ho // 2) * wo + wo // 2, 1] - (H - 1) / 2) < 1e-3   # viewport 1 looks at the centre
+    assert y.shape == (N * 14, Cc, ho, wo) and np.array_equal(y, orc.projects_forward(x, tf, ho, wo, near))
+    g = rng.standard_normal(y.shape).astype(np.float32)
+    gd, cnt = op.backward(dev(g))
+    rd, rc = orc.projects_backward(g, tf, N, Cc, H, W, near)
+    assert np.allclose(host(gd), rd, rtol=1e-5, atol=1e-5) and np.allclose(host(cnt), rc, rtol=1e-5, atol=1e-5)
+    lhs, rhs = float((y.astype(np.float64) * g).sum()), float((x.astype(np.float64) * host(gd)).sum())
+    assert abs(lhs - rhs) <= 1e-4 * (abs(lhs) + 1)
+    # the module: same output, gradient through autograd
+    mp = lo.MultiProject(ho, wo, fov, near, 0)
+    xt = dev(x).requires_grad_(True)
+    out = mp(xt)
+    assert np.array_equal(host(out.detach()), y)
+    out.backward(dev(g))
+    assert np.allclose(host(xt.grad), rd, rtol=1e-5, atol=1e-5)
+    # a constant image projects to the same constant (the four bilinear weights sum to one)
+    assert np.allclose(host(op.forward(dev(np.full((1, 1, H, W), 0.75, np.float32)))[0]), 0.75, atol=1e-6)
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)

@@ -78,7 +78,7 @@ WRAPPER_ARGS = {   # argument lists as the reference's own callers write them (t
     "DropGrad": (True,), "SSIM": (11,),
 }
 NEEDS_GPU_OR_OUT_OF_SCOPE = {"GDN": "allocates its parameters on cuda at construction (lic360_operator/GDN.py:44-47)",
-                             "MultiProject": "wraps ProjectsOp (out of scope, §8f.3)", "MaskConv2": "runs MaskConstrainOp on its weight at construction time only on a GPU (lic360_operator/MaskConstrain.py:27-33)",
+                              "MaskConv2": "runs MaskConstrainOp on its weight at construction time only on a GPU (lic360_operator/MaskConstrain.py:27-33)",
                              "ModuleSaver": "filesystem utility", "Logger": "filesystem utility"}
 
 
