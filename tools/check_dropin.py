@@ -43,7 +43,7 @@ def parse_bindings(text):
 def dummy(ctype):
     c = ctype.replace("std::", "").replace(" ", "")
     if c.startswith("vector<float>"):
-        return [0.0, 0.5]
+        return [0.0, 0.5] * 7                            # ProjectsOp: 14 viewport angles
     return {"int": 1, "float": 0.5, "bool": False, "string": "tmp", "double": 0.5}[c]
 
 
