@@ -75,7 +75,7 @@ WRAPPER_ARGS = {   # argument lists as the reference's own callers write them (t
     "CconvEc": (1, 144, 49, 5, True, False), "CconvEcBatch": (48, 1, 4, 5, 3, False, True), "TileExtract": (48, True),
     "TileExtractBatch": (48, True), "TileInput": (48, -3.5, 1, 3), "TileAdd": (48,), "EntropyGmmTable": (8, 3.5, 3, 65536),
     "EntropyBatchGmmTable": (8, 3.5, 3, 65536), "Dquant": (192, 8), "EntropyTable": (49, 65536), "Scale": (-1, 2 / 47.0), "Imp2mask": (48, 192),
-    "DropGrad": (True,), "SSIM": (11,),
+    "DropGrad": (True,), "SSIM": (11,), "MultiProject": (171, 256, 0.5, False, 0),
 }
 NEEDS_GPU_OR_OUT_OF_SCOPE = {"GDN": "allocates its parameters on cuda at construction (lic360_operator/GDN.py:44-47)",
                               "MaskConv2": "runs MaskConstrainOp on its weight at construction time only on a GPU (lic360_operator/MaskConstrain.py:27-33)",
