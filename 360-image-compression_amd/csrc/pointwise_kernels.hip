@@ -686,6 +686,40 @@ __global__ __launch_bounds__(256) void k_quant_weight_diff(const float *__restri
     }
     if (threadIdx.x == 0) weight_diff[pc * levels + j] = j ? red[0] * wq[pc * levels + j] : red[0];
 }
+// levels <= 8: one workgroup per channel, one pass: per-thread bucket sums S_q of (top - bottom) in registers, a tree over the workgroup,
+// then weight_diff[j] = S_j + S_{j+1} + ... (from the top level down)
+__global__ __launch_bounds__(256) void k_quant_weight_diff8(const float *__restrict__ bottom, const float *__restrict__ top, const float *__restrict__ qidx,
+                                                            const float *__restrict__ wq, float *__restrict__ weight_diff, int N, int C, long inner, int levels) {
+    __shared__ float red[8][256];
+    const int pc = blockIdx.x;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        const long base = ((long)n * C + pc) * inner;
+        for (long i = threadIdx.x; i < inner; i += 256) {
+            const int q = (int)qidx[base + i];
+            const float d = top[base + i] - bottom[base + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += q == k ? d : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float run = 0.0f;
+        for (int j = levels - 1; j >= 0; --j) {
+            run += red[j][0];
+            weight_diff[pc * levels + j] = j ? run * wq[pc * levels + j] : run;
+        }
+    }
+}
 __global__ void k_quant_data_diff(const float *__restrict__ top_diff0, const float *__restrict__ top_diff1, const float *__restrict__ bottom,
                                   const float *__restrict__ top, const float *__restrict__ qidx, const float *__restrict__ wq, float *__restrict__ data_diff,
                                   long total, long inner, int C, int levels, float alpha) {
@@ -712,8 +746,12 @@ LIC360_API int lic360_quant_backward(void *stream, const float *top_diff0, const
     ARG_CHECK(top_diff0 && bottom_data && top_data && qidx && wq && data_diff && weight_diff && n > 0 && c > 0 && h > 0 && w > 0 && levels > 0 &&
               (long)c * levels < (1l << 30));
     const long inner = (long)h * w, total = (long)n * c * inner;
-    hipLaunchKernelGGL(k_quant_weight_diff, dim3((unsigned)(c * levels)), dim3(256), 0, (hipStream_t)stream, bottom_data, top_data, qidx, wq, weight_diff, n, c,
-                       inner, levels);
+    if (levels <= 8)
+        hipLaunchKernelGGL(k_quant_weight_diff8, dim3((unsigned)c), dim3(256), 0, (hipStream_t)stream, bottom_data, top_data, qidx, wq, weight_diff, n, c, inner,
+                           levels);
+    else
+        hipLaunchKernelGGL(k_quant_weight_diff, dim3((unsigned)(c * levels)), dim3(256), 0, (hipStream_t)stream, bottom_data, top_data, qidx, wq, weight_diff, n,
+                           c, inner, levels);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_quant_data_diff, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, top_diff0, top_diff1, bottom_data, top_data, qidx, wq,
                        data_diff, total, inner, c, levels, top_alpha);

@@ -64,6 +64,17 @@ def measure(batches=(1, 32), device=0):
         tab = lic360.EntropyGmmTableOp(8, 3.5, 3, 65536, 1e-6, device, False)
         tn = torch.tensor([m], dtype=torch.int32)
         add("entropy_gmm_table (8192 symbols per image)", n, m * 72, lambda: tab.forward(w3, d3, m3, tn))      # (softmax / sigma floor are written back in place, as in the reference)
+        # the rows SURVEY.md 8f.3 / 8f.4 widened into: viewport projection of decoded RGB images, two training-side gradients
+        img = torch.rand((n, 3, 512, 1024), device=dev, generator=g)
+        pr = lic360.ProjectsOp(171, 256, [-0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, -0.5, 0, 0.5, 1, 0, 0],
+                               [0, 0, 0, 0, 0.25, 0.25, 0.25, 0.25, -0.25, -0.25, -0.25, -0.25, 0.5, -0.5], 0.5, False, device, False)
+        vp = n * 14 * 3 * 171 * 256 * 4
+        add("projects forward (14 viewports 171x256 of 512x1024 RGB)", n, vp + n * 14 * 171 * 256 * 8 + img.numel() * 4, lambda: pr.forward(img))
+        gp = torch.randn((n, 192, 36, 68), device=dev, generator=g)
+        add("sphere_pad backward (36x68 -> 32x64)", n, n * 192 * (32 * 64 + 36 * 68) * 4, lambda: pad2.backward(gp))
+        q.forward(y, wb, cnt, True)
+        gq = torch.randn(y.shape, device=dev, generator=g)
+        add("quant backward (data + level gradients)", n, 5 * y.numel() * 4, lambda: q.backward([gq, gq], y, q._top[0]))
     return rows
 
 
