@@ -1,0 +1,211 @@
+"""Analysis / synthesis transforms of the LIC360 codec on this backend: the networks that turn a 512x1024 ERP image
+into the (quantised latent, importance mask, importance map) triple the entropy coder consumes, and back.
+
+Architecture and parameter names follow the reference's inference models (test/model_zoo.py:8-205, 334-379) so that its checkpoints
+load with `load_state_dict`: the same module tree (`encoder.net.N...`, `decoder.net.N...`, `quant`, `imp`), built here from a few
+generic pieces.  The convolutions are library work (torch -> MIOpen, 105-116 nominal TFLOP/s for the 192-channel 3x3 layers on this
+GPU); what is native is everything around them: sphere pad / trim / cut-edge / pixel-shuffle / importance map /
+quantiser kernels of this package and the one-pass GDN (csrc/gdn_kernels.hip)."""
+import torch
+from torch import nn
+from lic360_operator import GDN, Dtow, SpherePad, SphereTrim, SphereCutEdge, QUANT, Dquant, SphereLatScaleNet, ImpMap
+
+
+def _conv(cin, cout, k, stride=1, pad=0):
+    return nn.Conv2d(cin, cout, k, stride, pad)
+
+
+class ResidualBlock(nn.Module):
+    """1x1 -> 3x3 -> 1x1 bottleneck on a refreshed apron (model_zoo.py:8-23)"""
+    def __init__(self, channels, device_id=0):
+        super().__init__()
+        half = channels // 2
+        self.pad = SpherePad(2, device_id, True)
+        self.conv1, self.relu1 = _conv(channels, half, 1), nn.PReLU(half)
+        self.conv2, self.relu2 = _conv(half, half, 3, 1, 1), nn.PReLU(half)
+        self.conv3 = _conv(half, channels, 1)
+        self.trim = SphereTrim(2, device_id)
+
+    def forward(self, x):
+        y = self.pad(x)
+        y = self.relu2(self.conv2(self.relu1(self.conv1(y))))
+        return self.trim(x + self.conv3(y))
+
+
+class AttentionBlock(nn.Module):
+    """x + trunk(x) * sigmoid-gate(x) (model_zoo.py:25-46)"""
+    def __init__(self, channels, device_id=0):
+        super().__init__()
+        three = lambda: [ResidualBlock(channels, device_id) for _ in range(3)]
+        self.trunk = nn.Sequential(*three())
+        self.attention = nn.Sequential(*three(), _conv(channels, channels, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        return x + self.trunk(x) * self.attention(x)
+
+
+class ResidualBlockV2(nn.Module):
+    """two 3x3 convs whose receptive field is fed by the apron (model_zoo.py:48-64)"""
+    def __init__(self, channels, device_id):
+        super().__init__()
+        self.pad = SpherePad(2, device_id, True)
+        self.conv1, self.relu1, self.trim1 = _conv(channels, channels, 3, 1, 1), nn.PReLU(channels), SphereTrim(1, device_id)
+        self.conv2, self.relu2, self.trim2 = _conv(channels, channels, 3, 1, 1), nn.PReLU(channels), SphereTrim(2, device_id)
+
+    def forward(self, x):
+        y = self.trim1(self.relu1(self.conv1(self.pad(x))))
+        return x + self.trim2(self.relu2(self.conv2(y)))
+
+
+class ResidualBlockDown(nn.Module):
+    """stride-2 stage with a GDN branch and a 1x1 stride-2 shortcut; `hidden=False` is the first stage, whose input has no apron yet
+    (model_zoo.py:66-95)"""
+    def __init__(self, channels, channel_in, device_id, hidden=True):
+        super().__init__()
+        self.pad1 = SpherePad(2, device_id, hidden)
+        self.conv1, self.relu1 = _conv(channel_in, channels, 3, 2, 3), nn.PReLU(channels)
+        self.trim = SphereTrim(2, device_id)
+        self.pad2 = SpherePad(2, device_id, True)
+        self.conv2, self.relu2 = _conv(channels, channels, 3, 1, 1), GDN(channels, device_id)
+        self.short_cut = _conv(channel_in, channels, 1, 2, 2)
+        self.hidden = hidden
+
+    def forward(self, x):
+        if self.hidden:
+            skip = self.short_cut(x)                                        # before pad1 refreshes the apron in place
+            y = self.pad1(x)
+        else:
+            x = self.pad1(x)
+            skip, y = None, x
+        y = self.pad2(self.trim(self.relu1(self.conv1(y))))
+        y = self.relu2(self.conv2(y))
+        return self.trim((self.short_cut(x) if skip is None else skip) + y)
+
+
+class SphereConv2(nn.Module):
+    def __init__(self, channel_in, channel_out, kernel_size, stride, pad=0, device_id=0):
+        super().__init__()
+        self.conv = _conv(channel_in, channel_out, kernel_size, stride, pad)
+        self.pad, self.trim = SpherePad(2, device_id, True), SphereTrim(2, device_id)
+
+    def forward(self, x):
+        return self.trim(self.conv(self.pad(x)))
+
+
+class SphereConv3(SphereConv2):
+    """the same with an out-of-place pad: the synthesis side's first layer, whose input has no apron (model_zoo.py:158-168)"""
+    def __init__(self, channel_in, channel_out, kernel_size, stride, pad=0, device_id=0):
+        super().__init__(channel_in, channel_out, kernel_size, stride, pad, device_id)
+        self.pad = SpherePad(2, device_id, False)
+
+
+class EncoderV2(nn.Module):
+    """image [n,3,512,1024] -> (code in (0,1) [n,cc,32,64], importance map [n,1,32,64]); every map carries a 2-cell sphere apron
+    until the final cut (model_zoo.py:108-143)"""
+    def __init__(self, channels, code_channels, device_id):
+        super().__init__()
+        d = device_id
+        self.net = nn.Sequential(ResidualBlockDown(channels, 3, d, False), ResidualBlockV2(channels, d), ResidualBlockDown(channels, channels, d),
+                                 AttentionBlock(channels, d), ResidualBlockV2(channels, d), ResidualBlockDown(channels, channels, d),
+                                 ResidualBlockV2(channels, d), SphereConv2(channels, channels, 3, 2, 3, d))
+        self.net2 = nn.Sequential(AttentionBlock(channels, d), _conv(channels, code_channels, 1), SphereCutEdge(2, d), nn.Sigmoid())
+        self.imp_net = nn.Sequential(ResidualBlockV2(channels, d), ResidualBlockV2(channels, d), _conv(channels, 1, 1), nn.Sigmoid(),
+                                     SphereCutEdge(2, d), SphereLatScaleNet(512 // 16, d))
+        self.imp_net[2].bias.data.fill_(3)
+
+    def forward(self, x):
+        t = self.net(x)
+        return self.net2(t), self.imp_net(t)
+
+
+class ResidualBlockUp(nn.Module):
+    """x2 upsampling stage: conv to 4c + pixel shuffle, an inverse-GDN branch, a 1x1 shortcut through its own shuffle (model_zoo.py:145-170)"""
+    def __init__(self, channels, device_id):
+        super().__init__()
+        d = device_id
+        self.pad1 = SpherePad(2, d, True)
+        self.conv1, self.relu1 = _conv(channels, channels * 4, 3, 1), nn.PReLU(channels * 4)
+        self.dtow1, self.trim1 = Dtow(2, True, d), SphereTrim(2, d)
+        self.pad2 = SpherePad(2, d, True)
+        self.conv2, self.relu2 = _conv(channels, channels, 3, 1, 1), GDN(channels, d, inverse=True)
+        self.short_cut = _conv(channels, channels * 4, 1)
+        self.cut_edge, self.dtow2, self.trim2 = SphereCutEdge(1, d), Dtow(2, True, d), SphereTrim(2, d)
+
+    def forward(self, x):
+        b = self.trim1(self.dtow1(self.relu1(self.conv1(self.pad1(x)))))
+        b = self.relu2(self.conv2(self.pad2(b)))
+        return self.trim2(b + self.dtow2(self.short_cut(self.cut_edge(x))))
+
+
+class Decoder(nn.Module):
+    """latent [n,cc,32,64] -> image [n,3,512,1024] (model_zoo.py:172-205)"""
+    def __init__(self, channels, code_channels, device_id):
+        super().__init__()
+        d = device_id
+        self.net = nn.Sequential(SphereConv3(code_channels, channels, 1, 1, 0, d), AttentionBlock(channels, d), ResidualBlockV2(channels, d),
+                                 ResidualBlockUp(channels, d), ResidualBlockV2(channels, d), ResidualBlockUp(channels, d), AttentionBlock(channels, d),
+                                 ResidualBlockV2(channels, d), ResidualBlockUp(channels, d), ResidualBlockV2(channels, d), SpherePad(2, d, True),
+                                 _conv(channels, 12, 3, 1, 1), SphereCutEdge(2, d), Dtow(2, True, d))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class CMP_Encoder(nn.Module):
+    """image -> (symbols 0..7 under the mask [n,48,64,128], mask [n,48,64,128], importance levels [n,1,32,64]): what EntEncoderFast /
+    FusedCodec.encode and ImpEntEncoderFast / FusedImpCodec.encode take (model_zoo.py:334-356)"""
+    def __init__(self, channels=192, code_channels=192, quant_levels=8, gpu_id=0):
+        super().__init__()
+        self.encoder = EncoderV2(channels, code_channels, gpu_id)
+        self.imp_level = code_channels // 4
+        self.quant = QUANT(code_channels, quant_levels, device_id=gpu_id, ntop=2)
+        self.imp = ImpMap(1, 0.0001, 0.0001, self.imp_level, 0.618, 0.618, 3, gpu_id, 2)
+        self.dtw1, self.dtw2 = Dtow(2, True, gpu_id), Dtow(2, True, gpu_id)
+
+    def forward(self, x):
+        code, imap = self.encoder(x)
+        tcode, mask, _ = self.imp(code, imap)
+        _, qy = self.quant(tcode)
+        return self.dtw1(qy), self.dtw2(mask), torch.sum(mask, dim=1, keepdim=True) / 4
+
+
+class CMP_Decoder(nn.Module):
+    """(symbols, mask) as decoded from the bitstreams -> image (model_zoo.py:358-379)"""
+    def __init__(self, channels=192, code_channels=192, quant_levels=8, gpu_id=0):
+        super().__init__()
+        self.decoder = Decoder(channels, code_channels, gpu_id)
+        self.imp_level = code_channels // 4
+        self.quant = Dquant(code_channels, quant_levels, device=gpu_id)
+        self.dtw1, self.dtw2 = Dtow(2, False, gpu_id), Dtow(2, False, gpu_id)
+
+    def forward(self, code, mask):
+        return self.decoder(self.quant(self.dtw1(code), self.dtw2(mask)))
+
+
+def transform_gflops(channels=192, code_channels=192, h=512, w=1024):
+    """nominal conv + GDN GFLOP of one analysis and one synthesis pass (2 flops per MAC; aprons counted: every map is 4 cells larger)"""
+    def conv(cin, cout, k, hh, ww):
+        return 2.0 * cin * cout * k * k * hh * ww
+    c, enc, dec = channels, 0.0, 0.0
+    bott = lambda hh, ww: conv(c, c // 2, 1, hh, ww) + conv(c // 2, c // 2, 3, hh, ww) + conv(c // 2, c, 1, hh, ww)
+    att = lambda hh, ww: 6 * bott(hh, ww) + conv(c, c, 1, hh, ww)
+    v2 = lambda hh, ww: 2 * conv(c, c, 3, hh, ww)
+    hh, ww, cin = h, w, 3
+    for stage in range(3):                                                  # three down stages
+        hh, ww = hh // 2 + 4, ww // 2 + 4
+        enc += conv(cin, c, 3, hh, ww) + conv(c, c, 3, hh, ww) + conv(c, c, 1, hh, ww) + conv(cin, c, 1, hh, ww) + v2(hh, ww)
+        if stage == 1:
+            enc += att(hh, ww)
+        cin = c
+        hh, ww = hh - 4, ww - 4
+    hh, ww = hh // 2 + 4, ww // 2 + 4                                       # 36 x 68
+    enc += conv(c, c, 3, hh, ww) + att(hh, ww) + conv(c, code_channels, 1, hh, ww) + 2 * v2(hh, ww) + conv(c, 1, 1, hh, ww)
+    dec += conv(code_channels, c, 1, hh, ww) + att(hh, ww) + v2(hh, ww)
+    for stage in range(3):                                                  # three up stages
+        dec += conv(c, 4 * c, 3, hh, ww) + conv(c, 4 * c, 1, hh, ww)
+        hh, ww = (hh - 4) * 2 + 4, (ww - 4) * 2 + 4
+        dec += conv(c, c, 3, hh, ww) + conv(c, c, 1, hh, ww) + v2(hh, ww)
+        if stage == 1:
+            dec += att(hh, ww)
+    dec += conv(c, 12, 3, hh, ww)
+    return enc / 1e9, dec / 1e9

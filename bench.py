@@ -298,6 +298,11 @@ def run_rank(args):
                                     "frac": r["frac_of_hbm_peak"], "avg_launch_ms": r["us"] * 1e-3, "images_per_launch": 32} for r in rows]
             except Exception as e:                                     # noqa: BLE001  (never lose the headline to a side table)
                 out["config"]["streaming_ops_error"] = repr(e)
+            try:       # the neighbouring row f1: analysis / synthesis transforms (library convs + native ops) and the one-pass GDN
+                import transform_bench
+                out["kernels"] += transform_bench.measure(batch=8, device=local)
+            except Exception as e:                                     # noqa: BLE001
+                out["config"]["transform_bench_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(layers, imp_layers, code_np[0:1], mask_np[0:1], level_np[0:1], img0[0], img0[1])
         print(json.dumps(out))

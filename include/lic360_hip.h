@@ -284,6 +284,11 @@ int lic360_projects_forward(void *stream, const float *x, const float *tf, float
 int lic360_projects_backward(void *stream, const float *top_diff, const float *tf, float *in_diff, float *count, int nc, int h, int w,
                              int h_out, int w_out, int nearest);
 
+/* ---- f1 generalised divisive normalisation, one pass (the reference's GDN is four torch kernels: lic360_operator/GDN.py:66-100) ------
+ * out[n,i,p] = x / sqrt(beta[i] + sum_j gamma[i,j] x[n,j,p]^2)   (inverse != 0: x * sqrt(...)); x / out [n][c][p] contiguous,
+ * gamma [c][c] and beta [c] are the effective (reparametrised) parameters; c in {16,32,48,64,96,128,192}; j summed in ascending order */
+int lic360_gdn(void *stream, const float *x, const float *gamma, const float *beta, float *out, int n, int c, long p, int inverse);
+
 /* Test hooks of the DEVICE arithmetic coder (A19/A20 as they run inside the fused codec): raw int32 tables [n][ncode+1]
  * (every table totals 65536), labels and an optional mask, all in device memory, through the same kernels the codec
  * launches -- encode: k_ac_encode; decode: k_dec_init + k_dec_plane (ncode == 8) or k_imp_dec_plane (other alphabets),

@@ -1,0 +1,134 @@
+"""The analysis / synthesis transforms on this backend (lic360_models.py): the one-pass GDN against its torch statement,
+blocks against index-only torch formulations, the reference's state_dict layout, and the whole codec end to end -- image -> transforms ->
+device-resident entropy codecs -> bitstreams -> transforms -> image -- with seeded random weights (no checkpoint exists offline)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lic():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    import lic360
+    return lic360
+
+
+def _pad_torch(x, pad):
+    W = x.shape[-1]
+    body = torch.cat([x[..., W - pad:], x, x[..., :pad]], -1)
+    def across(r):
+        r = torch.flip(r, (-1,))
+        return torch.cat([r[..., W - pad:], r, r[..., :pad]], -1)
+    return torch.cat([across(torch.flip(x[..., :pad, :], (-2,))), body, across(torch.flip(x[..., x.shape[-2] - pad:, :], (-2,)))], -2)
+
+
+def _refresh(x, pad=2):
+    """SpherePad in place: the apron of a padded map recomputed from its interior"""
+    return _pad_torch(x[..., pad:-pad, pad:-pad], pad)
+
+
+def _trim(x, pad):
+    y = torch.zeros_like(x)
+    y[..., pad:-pad, pad:-pad] = x[..., pad:-pad, pad:-pad]
+    return y
+
+
+@pytest.mark.parametrize("c,inverse", [(192, False), (192, True), (96, False), (16, True), (48, False)])
+def test_fused_gdn_matches_torch(lic, c, inverse):
+    g = torch.Generator(device="cuda:0").manual_seed(c)
+    x = torch.randn((2, c, 20, 37), device="cuda:0", generator=g)           # 740 positions: a ragged last tile
+    gamma = (torch.rand((c, c), device="cuda:0", generator=g) * 0.02 + 0.1 * torch.eye(c, device="cuda:0"))
+    beta = torch.rand((c,), device="cuda:0", generator=g) + 0.5
+    want = torch.sqrt(F.conv2d(x * x, gamma.view(c, c, 1, 1), beta))
+    want = x * want if inverse else x / want
+    got = lic.gdn_forward(x, gamma, beta, inverse)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), float((got - want).abs().max())
+    import lic360_operator as lo
+    m = lo.GDN(c, 0, inverse)
+    with torch.no_grad():
+        y_fused = m(x)
+    y_torch = m(x.clone().requires_grad_(True))                             # the recording path stays on torch
+    assert torch.allclose(y_fused, y_torch.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_blocks_match_index_only_torch(lic):
+    import lic360_models as lm
+    torch.manual_seed(3)
+    c = 16
+    x = _refresh(torch.randn((1, c, 12, 20), device="cuda:0"))              # a map with a valid 2-cell apron
+    with torch.no_grad():
+        blk = lm.ResidualBlockV2(c, 0).to("cuda:0")
+        y = _trim(blk.relu1(blk.conv1(_refresh(x))), 1)
+        want = x + _trim(blk.relu2(blk.conv2(y)), 2)
+        assert torch.allclose(blk(x.clone()), want, rtol=1e-5, atol=1e-5)
+        bt = lm.ResidualBlock(c, 0).to("cuda:0")
+        t = _refresh(x)
+        want = _trim(x + bt.conv3(bt.relu2(bt.conv2(bt.relu1(bt.conv1(t))))), 2)
+        assert torch.allclose(bt(x.clone()), want, rtol=1e-5, atol=1e-5)
+        dn = lm.ResidualBlockDown(c, c, 0).to("cuda:0")
+        t = _refresh(x)
+        yy = _refresh(_trim(dn.relu1(dn.conv1(t)), 2))
+        want = _trim(dn.short_cut(x) + dn.relu2(dn.conv2(yy)), 2)
+        assert torch.allclose(dn(x.clone()), want, rtol=1e-4, atol=1e-5)
+        up = lm.ResidualBlockUp(c, 0).to("cuda:0")
+        b = _trim(F.pixel_shuffle(up.relu1(up.conv1(_refresh(x))), 2), 2)
+        b = up.relu2(up.conv2(_refresh(b)))
+        want = _trim(b + F.pixel_shuffle(up.short_cut(x[..., 1:-1, 1:-1]), 2), 2)
+        assert torch.allclose(up(x.clone()), want, rtol=1e-4, atol=1e-5)
+
+
+def test_state_dict_layout_is_the_references(lic):
+    import lic360_models as lm
+    enc, dec = lm.CMP_Encoder(32, 32, 8, 0), lm.CMP_Decoder(32, 32, 8, 0)
+    ek, dk = set(enc.state_dict()), set(dec.state_dict())
+    for k in ("encoder.net.0.conv1.weight", "encoder.net.0.relu2.gamma", "encoder.net.0.short_cut.bias", "encoder.net.1.relu1.weight",
+              "encoder.net.3.trunk.2.conv3.weight", "encoder.net.3.attention.3.weight", "encoder.net.7.conv.weight", "encoder.net2.1.weight",
+              "encoder.imp_net.2.bias", "encoder.imp_net.5.net.0.weight", "encoder.imp_net.5.data", "quant.weight", "quant.count"):
+        assert k in ek, k
+    for k in ("decoder.net.0.conv.weight", "decoder.net.1.trunk.0.conv1.weight", "decoder.net.3.conv1.weight", "decoder.net.3.relu2.beta",
+              "decoder.net.3.short_cut.weight", "decoder.net.11.weight", "quant.weight"):
+        assert k in dk, k
+    assert tuple(enc.state_dict()["encoder.net.0.conv1.weight"].shape) == (32, 3, 3, 3)
+    assert tuple(dec.state_dict()["decoder.net.3.conv1.weight"].shape) == (128, 32, 3, 3)
+
+
+def test_whole_codec_end_to_end(lic):
+    """image -> analysis -> fused entropy codecs (latent + importance map) -> bytes -> decode -> synthesis -> image: what comes out of
+    the bitstreams is exactly what went in, so the reconstruction equals the one computed from the encoder-side symbols"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import lic360_models as lm
+    from lic360_fused import FusedCodec, FusedImpCodec
+    from util import make_main_params, make_imp_params
+    torch.manual_seed(11)
+    C = 32                                                                  # 8 groups of 4: the codec's structure at a fifth of the width
+    enc, dec = lm.CMP_Encoder(C, C, 8, 0).to("cuda:0").eval(), lm.CMP_Decoder(C, C, 8, 0).to("cuda:0").eval()
+    with torch.no_grad():
+        dec.quant.weight.copy_(enc.quant.weight)
+        img = torch.rand((2, 3, 512, 1024), device="cuda:0")
+        code, mask, levels = enc(img)
+    G = C // 4
+    assert tuple(code.shape) == (2, G, 64, 128) and tuple(mask.shape) == (2, G, 64, 128) and tuple(levels.shape) == (2, 1, 32, 64)
+    assert float(code.min()) >= 0 and float(code.max()) <= 7 and bool(((mask == 0) | (mask == 1)).all())
+    assert float(levels.min()) >= 0 and float(levels.max()) <= G and bool((levels == torch.round(levels)).all())
+    # the mask is the importance level unrolled over the groups (what Imp2mask rebuilds on the decoder side)
+    lv_up = levels.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    assert torch.equal(mask, (torch.arange(G, device="cuda:0").view(1, G, 1, 1) < lv_up).float())
+    fc = FusedCodec(G, 64, 128, max_batch=2)
+    fc.load_layers(make_main_params(5, G))
+    ic = FusedImpCodec(32, 64, max_batch=2, hidden_channels=3 * G, nsym=G + 1)
+    ic.load_layers(make_imp_params(5, cpg=3 * G, nsym=G + 1))
+    streams, istreams = fc.encode(code.contiguous(), mask.contiguous()), ic.encode(levels.contiguous())
+    assert all(len(s) > 0 for s in streams) and all(len(s) > 0 for s in istreams)
+    lv2 = ic.decode(istreams)
+    assert torch.equal(lv2, levels)
+    mask2 = (torch.arange(G, device="cuda:0").view(1, G, 1, 1) < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
+    code2 = fc.decode(streams, mask2)
+    assert torch.equal(code2, code * mask)
+    with torch.no_grad():
+        rec, rec_ref = dec(code2, mask2), dec(code * mask, mask)
+    assert tuple(rec.shape) == (2, 3, 512, 1024) and torch.equal(rec, rec_ref) and bool(torch.isfinite(rec).all())

@@ -1,0 +1,61 @@
+"""Analysis / synthesis transforms (lic360_models.py) at the reference's width (192 channels, 512x1024 ERPs): ms per image and nominal
+TFLOP/s (library convolutions through MIOpen + this package's sphere / shuffle / quantiser / GDN kernels), and the one-pass GDN against
+its four-kernel torch form.  Seeded random weights.  Writes one JSON document to stdout."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "360-image-compression_amd"))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+F32_PEAK_TFLOPS = 157.3
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def measure(batch=8, device=0, reps=3):
+    import lic360
+    import lic360_models as lm
+    dev = "cuda:%d" % device
+    torch.manual_seed(0)
+    enc, dec = lm.CMP_Encoder(gpu_id=device).to(dev).eval(), lm.CMP_Decoder(gpu_id=device).to(dev).eval()
+    ge, gd = lm.transform_gflops()
+    rows = []
+    with torch.no_grad():
+        img = torch.rand((batch, 3, 512, 1024), device=dev)
+        code, mask, _ = enc(img)
+        te = timed(lambda: enc(img), reps)
+        td = timed(lambda: dec(code, mask), reps)
+        for name, t, gf in (("analysis transform (image -> symbols, mask, importance map)", te, ge), ("synthesis transform (symbols, mask -> image)", td, gd)):
+            rows.append({"kernel": name, "bound": "mfma", "images_per_launch": batch, "ms_per_image": t / batch * 1e3, "nominal_gflop_per_image": gf,
+                         "achieved": gf * batch / t / 1e3, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s (nominal conv + GDN flops)",
+                         "frac": gf * batch / t / 1e3 / F32_PEAK_TFLOPS, "how": "torch conv2d (MIOpen) + native sphere / shuffle / quantiser / GDN kernels"})
+        # the one-pass GDN on the largest map (260 x 516 x 192) against its torch form
+        c = 192
+        x = torch.randn((batch, c, 260, 516), device=dev)
+        gamma, beta = torch.rand((c, c), device=dev) * 0.02 + 0.1 * torch.eye(c, device=dev), torch.rand((c,), device=dev) + 0.5
+        out = torch.empty_like(x)
+        t_f = timed(lambda: lic360.gdn_forward(x, gamma, beta, False, out), 5)
+        t_t = timed(lambda: x / torch.sqrt(F.conv2d(x * x, gamma.view(c, c, 1, 1), beta)), 5)
+        fl = 2.0 * c * c * x.numel() / c
+        rows.append({"kernel": "gdn one pass (192 ch, 260x516)", "bound": "mfma", "images_per_launch": batch, "avg_launch_ms": t_f * 1e3,
+                     "achieved": fl / t_f / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / t_f / 1e12 / F32_PEAK_TFLOPS,
+                     "algorithmic_bytes_per_launch": 2.0 * x.numel() * 4, "GBps": 2.0 * x.numel() * 4 / t_f / 1e9,
+                     "torch_four_kernel_form_ms": t_t * 1e3, "speedup_vs_torch": t_t / t_f})
+    return rows
+
+
+if __name__ == "__main__":
+    print(json.dumps({"rows": measure()}, indent=1))
