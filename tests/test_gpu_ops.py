@@ -761,8 +761,13 @@ def test_operator_extras_plain_torch(lic):
     y = torch.ones(3, device="cuda:0", requires_grad=True)
     lo.DropGrad(True)(y).sum().backward()
     assert float(y.grad.abs().sum()) == 0.0
+    # the demo's viewport-metric stage: 14 viewports of 171 x 256 per image, PSNR / SSIM of identical inputs
+    pr = lo.MultiProject(171, int(171 * 1.5), 0.5, False, 0)
+    img = torch.rand((1, 3, 512, 1024), device="cuda:0")
+    v = pr(img)
+    assert tuple(v.shape) == (14, 3, 171, 256) and abs(float(lo.SSIM(11, 3)(v, v.clone())) - 1.0) < 1e-5
     with pytest.raises(NotImplementedError):
-        lo.MultiProject(171, 171)
+        lic.ViewportOp(90.0, 8, 8, 0, False)
 
 
 # ------------------------------------------------------------------ encode-order conv on 16x16x4 MFMAs, direct C-ABI call
