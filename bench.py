@@ -108,7 +108,25 @@ def cpu_baseline(layers, imp_layers, code, mask, levels, gpu_bytes, gpu_imp_byte
     assert np.array_equal(out, code * mask) and np.array_equal(lv, levels)
     same = bool(data == gpu_bytes and imp == gpu_imp_bytes)
     assert same, "GPU bitstream of image 0 differs from the oracle's"
+    # BASELINE.json configs[0] beside it: the range coder alone, one thread, 393 216 symbols (= 32 x 64 x 192) on the fixed 9-entry CDF
+    import oracle as orc
+    rng = np.random.default_rng(1234)
+    cdf = np.array([0, 1200, 5200, 14000, 32768, 51536, 60336, 64336, 65536], np.int32)
+    sym = np.searchsorted(cdf, rng.integers(0, 65536, 393216), side="right").astype(np.int32) - 1
+    tabs = np.tile(cdf, (sym.size, 1))
+    c0 = time.time()
+    e = orc.Encoder()
+    e.encode(tabs, 8, sym, None, sym.size)
+    blob = e.finish()
+    c1 = time.time()
+    d = orc.Decoder(blob)
+    back = d.decode(tabs, 8, None, sym.size)
+    d.close()
+    c2 = time.time()
+    assert np.array_equal(back.astype(np.int32), sym)
     return {"value": PIXELS / (t2 - t0) / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+            "coder_single_thread": {"symbols": int(sym.size), "bytes": len(blob), "encode_Msym_per_s": sym.size / (c1 - c0) / 1e6,
+                                    "decode_Msym_per_s": sym.size / (c2 - c1) / 1e6, "note": "configs[0]: range coder only, fixed CDF, one host thread"},
             "encode_s": t1 - t0, "decode_s": t2 - t1, "gpu_bytes_equal_oracle_bytes": same,
             "sample": "oracle encode + decode of ONE whole 512x1024 image of the timed batch (image 0: latent 48x64x128 + 32x64 importance "
                       "map, full 12-layer x3 model), %.1f s on %d threads" % (t2 - t0, cores)}
