@@ -134,3 +134,165 @@ LIC360_API int lic360_projects_backward(void *stream, const float *top_diff, con
     LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------- CppOp
+// ERP -> Craster parabolic projection (extension/CPP.hpp:6-11, CPP_cuda.cu:11-22,46-104): row th keeps ww(th) centred columns, resampled
+// from the whole ERP row; per-row constants on the host (libm where the reference runs libdevice), one output element per thread.
+__global__ void k_cpp_forward(const float *__restrict__ in, float *__restrict__ out, float *__restrict__ mask, const int *__restrict__ ws,
+                              const float *__restrict__ theta, long total, int NC, int H, int W, float pi) {
+    GRID_STRIDE(index, total) {
+        const int tw = (int)(index % W), th = (int)((index / W) % H);
+        const long tn = index / W / H;
+        const int wstart = ws[2 * th], ww = ws[2 * th + 1], wend = wstart + ww;
+        const bool outside = tw < wstart || tw >= wend;
+        if (mask) mask[index] = outside ? 0.0f : 1.0f;
+        if (outside) { out[index] = 0.0f; continue; }
+        const float t = theta[th];
+        const float phi = (float)((tw - wstart + 0.5) / ww);
+        float qw = (float)(phi * W - 0.5);
+        const float qh = (float)((0.5 - t / pi) * H - 0.5);
+        qw = qw < 0 ? qw + W : qw;
+        const int wa = (int)qw, wb = (wa + 1) % W;
+        const float wf = wa + 1 - qw;
+        if (qh < 0) {
+            const long pb = tn * H * W;
+            out[index] = wf * in[pb + wa] + (1 - wf) * in[pb + wb];
+        } else if (qh >= H) {
+            const long pb = (tn * H + H - 1) * W;
+            out[index] = wf * in[pb + wa] + (1 - wf) * in[pb + wb];
+        } else {
+            const int ha = (int)qh, hf = (int)(ha + 1 - qh);                 // an int in the reference: 0 or 1
+            const long r0 = tn * H + ha, r1 = r0 + 1 < (long)NC * H ? r0 + 1 : r0;   // "next row" of the flattened array, as the reference
+            out[index] = wf * hf * in[r0 * W + wa] + (1 - wf) * hf * in[r0 * W + wb] + wf * (1 - hf) * in[r1 * W + wa] + (1 - wf) * (1 - hf) * in[r1 * W + wb];
+        }
+    }
+}
+// ws_dev [h][2] ints and theta_dev [h] floats are scratch the caller owns (filled here for this height / width)
+LIC360_API int lic360_cpp_rows(void *stream, int *ws_dev, float *theta_dev, int h, int w) {
+    ARG_CHECK(ws_dev && theta_dev && h > 0 && w > 0);
+    std::vector<int> ws((size_t)2 * h);
+    std::vector<float> th((size_t)h);
+    for (int i = 0; i < h; ++i) {
+        const float t = 3 * asinf((float)(0.5 - (i + 0.5) / h));
+        const int ww = (int)((2 * cosf(2 * t / 3) - 1) * w + 0.999);
+        th[i] = t;
+        ws[2 * i] = (w - ww) / 2;
+        ws[2 * i + 1] = ww;
+    }
+    hipError_t e = hipMemcpyAsync(ws_dev, ws.data(), ws.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(theta_dev, th.data(), th.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    HIP_TRY(e);
+    return 0;
+}
+LIC360_API int lic360_cpp_forward(void *stream, const float *x, float *out, float *mask, const int *ws_dev, const float *theta_dev, int nc, int h, int w) {
+    ARG_CHECK(x && out && ws_dev && theta_dev && nc > 0 && h > 0 && w > 0);
+    const long total = (long)nc * h * w;
+    hipLaunchKernelGGL(k_cpp_forward, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, x, out, mask, ws_dev, theta_dev, total, nc, h, w,
+                       (float)acos(-1));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- ViewportOp
+// One rectilinear viewport per sample, looking at (theta, phi) given per call as a device tensor (extension/viewport.hpp:7-13,
+// viewport_cuda.cu).  Per-sample trigonometry on the device (the angles live there); the pinhole constants on the host.
+struct VpConsts { float w_stride, h_stride, c_x, c_y, wangle; };
+static VpConsts vp_consts(float fov_deg, int ho, int wo) {
+    const float pi = (float)acos(-1.0), fov = fov_deg / 180 * pi, hfov = fov * ho / wo / 2, wfov = fov / 2, half = pi / 2;
+    VpConsts k;
+    k.c_x = (float)(wo / 2.0);
+    k.c_y = (float)(ho / 2.0);
+    k.wangle = half - wfov;
+    k.w_stride = 2 * sinf(wfov) / sinf(k.wangle) / wo;
+    k.h_stride = 2 * sinf(hfov) / sinf(half - hfov) / ho;
+    return k;
+}
+// yaw by theta about z, then pitch by phi about the yawed y axis, written out (viewport_cuda.cu:23-58)
+__global__ void k_vp_rota(const float *__restrict__ theta_phi, float *__restrict__ r, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a11 = cosf(theta_phi[2 * i]), a12 = -sinf(theta_phi[2 * i]), a21 = -a12, a22 = a11;
+    const float c = cosf(theta_phi[2 * i + 1]), s = sinf(theta_phi[2 * i + 1]);
+    const float b11 = c + (1 - c) * a12 * a12, b12 = (1 - c) * a12 * a22, b13 = -s * a22, b21 = b12, b22 = c + (1 - c) * a22 * a22, b23 = s * a12;
+    const float b31 = s * a22, b32 = -s * a12, b33 = c;
+    float *o = r + 9 * i;
+    o[0] = b11 * a11 + b12 * a21 + b13 * 0.0f;  o[1] = b11 * a12 + b12 * a22 + b13 * 0.0f;  o[2] = b11 * 0.0f + b12 * 0.0f + b13 * 1.0f;
+    o[3] = b21 * a11 + b22 * a21 + b23 * 0.0f;  o[4] = b21 * a12 + b22 * a22 + b23 * 0.0f;  o[5] = b21 * 0.0f + b22 * 0.0f + b23 * 1.0f;
+    o[6] = b31 * a11 + b32 * a21 + b33 * 0.0f;  o[7] = b31 * a12 + b32 * a22 + b33 * 0.0f;  o[8] = b31 * 0.0f + b32 * 0.0f + b33 * 1.0f;
+}
+__global__ void k_vp_rays(float *__restrict__ rays0, const float *__restrict__ rota, float *__restrict__ rays, float *__restrict__ tf, long count,
+                          int ho, int wo, VpConsts k, float hx, float hy, float pi) {
+    GRID_STRIDE(i, count) {
+        const int w = (int)(i % wo), h = (int)((i / wo) % ho), tb = (int)(i / ((long)ho * wo));
+        const float x = 1.0f, y = (float)((w - k.c_x + 0.5) * k.w_stride), z = (float)((h - k.c_y + 0.5) * k.h_stride);
+        const float r = sqrtf(x * x + y * y + z * z);
+        const float xa = x / r, xb = y / r, xc = -z / r;
+        rays0[i * 3] = xa;  rays0[i * 3 + 1] = xb;  rays0[i * 3 + 2] = xc;
+        const float *m = rota + 9 * tb;
+        const float vx = xa * m[0] + xb * m[1] + xc * m[2], vy = xa * m[3] + xb * m[4] + xc * m[5], vz = xa * m[6] + xb * m[7] + xc * m[8];
+        rays[i * 3] = vx;  rays[i * 3 + 1] = vy;  rays[i * 3 + 2] = vz;
+        const float lat = asinf(vz);
+        float t = atanf(vy / vx);
+        if (vx <= 0) t = vy > 0 ? t + pi : t - pi;
+        tf[i * 2] = (float)((0.5 * t / pi + 0.5) * hx - 0.5);
+        tf[i * 2 + 1] = (float)((0.5 - lat / pi) * hy - 0.5);
+    }
+}
+__global__ void k_vp_sample(const float *__restrict__ in, const float *__restrict__ tf, float *__restrict__ out, long total, int C, int hs, int ws, int inner) {
+    GRID_STRIDE(index, total) {
+        const int ps = (int)(index % inner);
+        const long tbase = index / inner, tn = tbase / C;
+        const float2 f = ((const float2 *)tf)[tn * inner + ps];
+        const int tw = (int)floorf(f.x), th = (int)floorf(f.y);
+        const int ah = th > 0 ? th : 0, bh = th + 1 >= hs ? hs - 1 : th + 1, aw = (tw + ws) % ws, bw = (tw + 1) % ws;
+        const float tx = f.x - tw, ty = f.y - th, ntx = (float)(1. - tx), nty = (float)(1. - ty);
+        const float *img = in + tbase * hs * ws;
+        out[index] = img[ah * ws + aw] * ntx * nty + img[ah * ws + bw] * tx * nty + img[bh * ws + aw] * ntx * ty + img[bh * ws + bw] * tx * ty;
+    }
+}
+__global__ void k_vp_angles(float *__restrict__ tf, long count, float hx, float hy, float pi) {
+    GRID_STRIDE(i, count) {
+        tf[i * 2] = (float)(((tf[i * 2] + 0.5) / hx - 0.5) * pi * 2);
+        tf[i * 2 + 1] = (float)((0.5 - (tf[i * 2 + 1] + 0.5) / hy) * pi);
+    }
+}
+LIC360_API int lic360_viewport_rota(void *stream, const float *theta_phi, float *rota, int n) {
+    ARG_CHECK(theta_phi && rota && n > 0);
+    hipLaunchKernelGGL(k_vp_rota, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, theta_phi, rota, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+// out [n,c,ho,wo]; rays0, rays [n,ho,wo,3]; rota [n,9]; tf [n,ho,wo,2]: on return the (longitude, latitude) of every viewport pixel
+LIC360_API int lic360_viewport_forward(void *stream, const float *x, const float *theta_phi, float *out, float *rays0, float *rota, float *rays, float *tf,
+                                       int n, int c, int h, int w, int ho, int wo, float fov_deg) {
+    ARG_CHECK(x && theta_phi && out && rays0 && rota && rays && tf && n > 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const float pi = (float)acos(-1.0);
+    const VpConsts k = vp_consts(fov_deg, ho, wo);
+    const long count = (long)n * ho * wo, total = count * c;
+    hipLaunchKernelGGL(k_vp_rota, dim3((n + 63) / 64), dim3(64), 0, s, theta_phi, rota, n);
+    hipLaunchKernelGGL(k_vp_rays, dim3(lic360_blocks(count)), dim3(256), 0, s, rays0, rota, rays, tf, count, ho, wo, k, (float)w, (float)h, pi);
+    hipLaunchKernelGGL(k_vp_sample, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, x, tf, out, total, c, h, w, ho * wo);
+    hipLaunchKernelGGL(k_vp_angles, dim3(lic360_blocks(count)), dim3(256), 0, s, tf, count, (float)w, (float)h, pi);
+    LAUNCH_CHECK();
+    return 0;
+}
+__global__ void k_vp_xy(const float *__restrict__ next, const float *__restrict__ rota, float *__restrict__ xy, int n, float rad, float x_bias, float y_bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *y = rota + 9 * i;
+    const float ts = sinf(next[2 * i]), tc = cosf(next[2 * i]), fs = sinf(next[2 * i + 1]), fc = cosf(next[2 * i + 1]);
+    const float xa = tc * fc, xb = ts * fc, xc = fs;
+    const float gamma = rad / (xa * y[0] + xb * y[3] + xc * y[6]);
+    xy[2 * i] = (float)(gamma * (xa * y[1] + xb * y[4] + xc * y[7]) - 0.5 + x_bias);
+    xy[2 * i + 1] = (float)(-gamma * (xa * y[2] + xb * y[5] + xc * y[8]) - 0.5 + y_bias);
+}
+LIC360_API int lic360_viewport_xy(void *stream, const float *theta_phi_next, const float *rota, float *xy, int n, int ho, int wo, float fov_deg) {
+    ARG_CHECK(theta_phi_next && rota && xy && n > 0 && ho > 0 && wo > 0);
+    const VpConsts k = vp_consts(fov_deg, ho, wo);
+    hipLaunchKernelGGL(k_vp_xy, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, theta_phi_next, rota, xy, n, (float)(0.5 * wo * tan((double)k.wangle)),
+                       (float)(0.5 * wo), (float)(0.5 * ho));
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -284,6 +284,21 @@ int lic360_projects_forward(void *stream, const float *x, const float *tf, float
 int lic360_projects_backward(void *stream, const float *top_diff, const float *tf, float *in_diff, float *count, int nc, int h, int w,
                              int h_out, int w_out, int nearest);
 
+/* CppOp: ERP -> Craster parabolic projection.  lic360_cpp_rows fills the per-row column window ws [h][2] = (first column, count) and the
+ * row angle theta [h] (host computes, device write); lic360_cpp_forward resamples x [nc][h][w] row by row, zero outside the window; mask
+ * (may be NULL) gets 1 inside / 0 outside     extension/CPP.hpp:6-11, CPP_cuda.cu:11-22,46-122 */
+int lic360_cpp_rows(void *stream, int *ws_dev, float *theta_dev, int h, int w);
+int lic360_cpp_forward(void *stream, const float *x, float *out, float *mask, const int *ws_dev, const float *theta_dev, int nc, int h, int w);
+
+/* ViewportOp: one rectilinear viewport per sample looking at theta_phi [n,2] (radians, device), field of view fov_deg.
+ * cal_rota_matrix -> rota [n,9]; forward -> out [n,c,ho,wo], rays0 / rays [n,ho,wo,3] (camera frame / rotated), tf [n,ho,wo,2] = (longitude,
+ * latitude) of every viewport pixel; get_viewport_xy -> where the directions theta_phi_next fall in the current viewports, in pixels
+ *                                            extension/viewport.hpp:7-13, viewport_cuda.cu:8-289 (its backward returns nothing) */
+int lic360_viewport_rota(void *stream, const float *theta_phi, float *rota, int n);
+int lic360_viewport_forward(void *stream, const float *x, const float *theta_phi, float *out, float *rays0, float *rota, float *rays, float *tf,
+                            int n, int c, int h, int w, int ho, int wo, float fov_deg);
+int lic360_viewport_xy(void *stream, const float *theta_phi_next, const float *rota, float *xy, int n, int ho, int wo, float fov_deg);
+
 /* ---- f1 generalised divisive normalisation, one pass (the reference's GDN is four torch kernels: lic360_operator/GDN.py:66-100) ------
  * out[n,i,p] = x / sqrt(beta[i] + sum_j gamma[i,j] x[n,j,p]^2)   (inverse != 0: x * sqrt(...)); x / out [n][c][p] contiguous,
  * gamma [c][c] and beta [c] are the effective (reparametrised) parameters; c in {16,32,48,64,96,128,192}; j summed in ascending order */

@@ -931,3 +931,121 @@ ORC_API void orc_projects_backward(const float *top_diff, const float *tf, float
     free(acc);
     free(cnt);
 }
+
+/* ------------------------------------------------------------------------------------
+ * CppOp: ERP -> Craster parabolic projection, row by row (extension/CPP_cuda.cu:11-22,46-85).  Row th keeps ww = int((2 cos(2 t / 3) - 1) W
+ * + 0.999) centred columns, t = 3 asin(0.5 - (th + 0.5) / H), resampled from the whole ERP row with linear interpolation in longitude;
+ * the vertical weight `hf` is an int in the reference (so it is 0 or 1): kept.  out / mask [NC][H][W]
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_cpp_forward(const float *in, float *out, float *mask, int NC, int H, int W) {
+    const float pi = (float)acos(-1);
+    for (int th = 0; th < H; ++th) {
+        const float t = 3 * asinf((float)(0.5 - (th + 0.5) / H));
+        const int ww = (int)((2 * cosf(2 * t / 3) - 1) * W + 0.999), wstart = (W - ww) / 2, wend = wstart + ww;
+        for (int tn = 0; tn < NC; ++tn)
+            for (int tw = 0; tw < W; ++tw) {
+                const long index = ((long)tn * H + th) * W + tw;
+                if (mask) mask[index] = (tw < wstart || tw >= wend) ? 0.0f : 1.0f;
+                if (tw < wstart || tw >= wend) { out[index] = 0; continue; }
+                float phi = (float)((tw - wstart + 0.5) / ww);
+                float qw = (float)(phi * W - 0.5), qh = (float)((0.5 - t / pi) * H - 0.5);
+                qw = qw < 0 ? qw + W : qw;
+                const int wa = (int)qw, wb = (wa + 1) % W;
+                const float wf = wa + 1 - qw;
+                if (qh < 0) {
+                    const long pb = (long)tn * H * W;
+                    out[index] = wf * in[pb + wa] + (1 - wf) * in[pb + wb];
+                } else if (qh >= H) {
+                    const long pb = ((long)tn * H + H - 1) * W;
+                    out[index] = wf * in[pb + wa] + (1 - wf) * in[pb + wb];
+                } else {
+                    /* the reference addresses "the next row" of the flattened [NC*H][W] array even from the last row of a plane
+                     * (it then reads the next plane's first row); kept, clamped to the array for the very last row */
+                    const int ha = (int)qh, hf = (int)(ha + 1 - qh);
+                    const long r0 = (long)tn * H + ha, r1 = r0 + 1 < (long)NC * H ? r0 + 1 : r0;
+                    out[index] = wf * hf * in[r0 * W + wa] + (1 - wf) * hf * in[r0 * W + wb] + wf * (1 - hf) * in[r1 * W + wa] + (1 - wf) * (1 - hf) * in[r1 * W + wb];
+                }
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * ViewportOp (extension/viewport.hpp:7-13, viewport_cuda.cu): one rectilinear viewport per sample, looking at (theta, phi) [radians],
+ * field of view fov_deg; fp32 with libm.  Outputs as the reference returns them: view [n,c,ho,wo], rays0 [n,ho,wo,3] (camera frame),
+ * rota [n,9], rays [n,ho,wo,3] (rotated), tf [n,ho,wo,2] = (longitude, latitude) of every viewport pixel in radians.
+ * ---------------------------------------------------------------------------------- */
+static void orc_vp_consts(float fov_deg, int ho, int wo, float *w_stride, float *h_stride, float *c_x, float *c_y, float *wangle) {
+    const float pi = (float)acos(-1.0), fov = fov_deg / 180 * pi;
+    const float hfov = fov * ho / wo / 2, wfov = fov / 2, pi_2 = pi / 2;
+    *c_x = (float)(wo / 2.0);
+    *c_y = (float)(ho / 2.0);
+    *wangle = pi_2 - wfov;
+    const float hangle = pi_2 - hfov;
+    *w_stride = 2 * sinf(wfov) / sinf(*wangle) / wo;
+    *h_stride = 2 * sinf(hfov) / sinf(hangle) / ho;
+}
+ORC_API void orc_viewport_rota(const float *theta_phi, float *r, int n) {
+    for (int i = 0; i < n; ++i) {
+        const float a11 = cosf(theta_phi[2 * i]), a12 = -sinf(theta_phi[2 * i]), a13 = 0, a21 = -a12, a22 = a11, a23 = 0, a31 = 0, a32 = 0, a33 = 1;
+        const float c = cosf(theta_phi[2 * i + 1]), sn = sinf(theta_phi[2 * i + 1]);
+        const float b11 = c + (1 - c) * a12 * a12, b12 = (1 - c) * a12 * a22, b13 = -sn * a22, b21 = (1 - c) * a12 * a22, b22 = c + (1 - c) * a22 * a22,
+                    b23 = sn * a12, b31 = sn * a22, b32 = -sn * a12, b33 = c;
+        float *o = r + 9 * i;
+        o[0] = b11 * a11 + b12 * a21 + b13 * a31;  o[1] = b11 * a12 + b12 * a22 + b13 * a32;  o[2] = b11 * a13 + b12 * a23 + b13 * a33;
+        o[3] = b21 * a11 + b22 * a21 + b23 * a31;  o[4] = b21 * a12 + b22 * a22 + b23 * a32;  o[5] = b21 * a13 + b22 * a23 + b23 * a33;
+        o[6] = b31 * a11 + b32 * a21 + b33 * a31;  o[7] = b31 * a12 + b32 * a22 + b33 * a32;  o[8] = b31 * a13 + b32 * a23 + b33 * a33;
+    }
+}
+ORC_API void orc_viewport_forward(const float *in, const float *theta_phi, float *out, float *rays0, float *rota, float *rays, float *tf,
+                                  int N, int C, int H, int W, int ho, int wo, float fov_deg) {
+    const float pi = (float)acos(-1.0);
+    float w_stride, h_stride, c_x, c_y, wangle;
+    orc_vp_consts(fov_deg, ho, wo, &w_stride, &h_stride, &c_x, &c_y, &wangle);
+    orc_viewport_rota(theta_phi, rota, N);
+    const int inner = ho * wo;
+    const float hx = (float)W, hy = (float)H;
+    for (long i = 0; i < (long)N * inner; ++i) {
+        const int w = (int)(i % wo), h = (int)((i / wo) % ho), tb = (int)(i / inner);
+        float x = 1.0f, y = (float)((w - c_x + 0.5) * w_stride), z = (float)((h - c_y + 0.5) * h_stride);
+        float r = sqrtf(x * x + y * y + z * z);
+        rays0[i * 3] = x / r;  rays0[i * 3 + 1] = y / r;  rays0[i * 3 + 2] = -z / r;
+        const float *m = rota + 9 * tb;
+        const float xa = rays0[i * 3], xb = rays0[i * 3 + 1], xc = rays0[i * 3 + 2];
+        rays[i * 3] = xa * m[0] + xb * m[1] + xc * m[2];
+        rays[i * 3 + 1] = xa * m[3] + xb * m[4] + xc * m[5];
+        rays[i * 3 + 2] = xa * m[6] + xb * m[7] + xc * m[8];
+        float lat = asinf(rays[i * 3 + 2]), tx = rays[i * 3], ty = rays[i * 3 + 1], t = atanf(ty / tx);
+        if (tx <= 0) t = ty > 0 ? t + pi : t - pi;
+        tf[i * 2] = (float)((0.5 * t / pi + 0.5) * hx - 0.5);
+        tf[i * 2 + 1] = (float)((0.5 - lat / pi) * hy - 0.5);
+    }
+    for (long index = 0; index < (long)N * C * inner; ++index) {
+        const int ps = (int)(index % inner);
+        const long tbase = index / inner, tn = tbase / C;
+        const float fx = tf[(tn * inner + ps) * 2], fy = tf[(tn * inner + ps) * 2 + 1];
+        const int tw = (int)floorf(fx), th = (int)floorf(fy);
+        const int ah = th > 0 ? th : 0, bh = th + 1 >= H ? H - 1 : th + 1, aw = (tw + W) % W, bw = (tw + 1) % W;
+        const float tx = fx - tw, ty = fy - th, ntx = (float)(1. - tx), nty = (float)(1. - ty);
+        const float *img = in + tbase * H * W;
+        out[index] = img[ah * W + aw] * ntx * nty + img[ah * W + bw] * tx * nty + img[bh * W + aw] * ntx * ty + img[bh * W + bw] * tx * ty;
+    }
+    for (long i = 0; i < (long)N * inner; ++i) {
+        tf[i * 2] = (float)(((tf[i * 2] + 0.5) / hx - 0.5) * pi * 2);
+        tf[i * 2 + 1] = (float)((0.5 - (tf[i * 2 + 1] + 0.5) / hy) * pi);
+    }
+}
+/* get_viewport_xy: where the direction (theta, phi) of each sample falls in that sample's current viewport, in viewport pixels
+ * (extension/viewport_cuda.cu:232-289) */
+ORC_API void orc_viewport_xy(const float *theta_phi_next, const float *rota, float *xy, int n, int ho, int wo, float fov_deg) {
+    float w_stride, h_stride, c_x, c_y, wangle;
+    orc_vp_consts(fov_deg, ho, wo, &w_stride, &h_stride, &c_x, &c_y, &wangle);
+    const float rad = (float)(0.5 * wo * tan((double)wangle)), x_bias = (float)(0.5 * wo), y_bias = (float)(0.5 * ho);
+    for (int i = 0; i < n; ++i) {
+        const float *y = rota + 9 * i;
+        const float ts = sinf(theta_phi_next[2 * i]), tc = cosf(theta_phi_next[2 * i]), fs = sinf(theta_phi_next[2 * i + 1]), fc = cosf(theta_phi_next[2 * i + 1]);
+        const float xa = tc * fc, xb = ts * fc, xc = fs;
+        const float tmp = xa * y[0] + xb * y[3] + xc * y[6], gamma = rad / tmp;
+        xy[2 * i] = (float)(gamma * (xa * y[1] + xb * y[4] + xc * y[7]) - 0.5 + x_bias);
+        xy[2 * i + 1] = (float)(-gamma * (xa * y[2] + xb * y[5] + xc * y[8]) - 0.5 + y_bias);
+    }
+}

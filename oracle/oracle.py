@@ -476,3 +476,35 @@ def projects_backward(g, tf, N, Cc, H, W, nearest=False):
     d, c = np.empty((N, Cc, H, W), np.float32), np.empty((N, Cc, H, W), np.float32)
     lib.orc_projects_backward(f32(g), f32(tf), d, c, N * Cc, H, W, inner, int(nearest))
     return d, c
+
+
+# ---------------------------------------------------------------- CppOp (Craster parabolic projection)
+lib.orc_cpp_forward.argtypes = [_f, _f, C.c_void_p, C.c_int, C.c_int, C.c_int]
+
+
+def cpp_forward(x, want_mask=False):
+    N, Cc, H, W = x.shape
+    out = np.empty((N, Cc, H, W), np.float32)
+    mask = np.empty((N, Cc, H, W), np.float32) if want_mask else None
+    lib.orc_cpp_forward(f32(x), out, _fp(mask), N * Cc, H, W)
+    return out, mask
+
+
+# ---------------------------------------------------------------- ViewportOp
+lib.orc_viewport_forward.argtypes = [_f] * 7 + [C.c_int] * 6 + [C.c_float]
+lib.orc_viewport_xy.argtypes = [_f, _f, _f, C.c_int, C.c_int, C.c_int, C.c_float]
+
+
+def viewport_forward(x, theta_phi, ho, wo, fov_deg):
+    N, Cc, H, W = x.shape
+    out, r0 = np.empty((N, Cc, ho, wo), np.float32), np.empty((N, ho, wo, 3), np.float32)
+    rota, rays, tf = np.empty((N, 9), np.float32), np.empty((N, ho, wo, 3), np.float32), np.empty((N, ho, wo, 2), np.float32)
+    lib.orc_viewport_forward(f32(x), f32(theta_phi), out, r0, rota, rays, tf, N, Cc, H, W, ho, wo, fov_deg)
+    return out, r0, rota, rays, tf
+
+
+def viewport_xy(theta_phi_next, rota, ho, wo, fov_deg):
+    n = theta_phi_next.shape[0]
+    xy = np.empty((n, 2), np.float32)
+    lib.orc_viewport_xy(f32(theta_phi_next), f32(rota), xy, n, ho, wo, fov_deg)
+    return xy

@@ -603,6 +603,56 @@ def test_projects_op_viewports(lic, near):
     assert np.allclose(host(op.forward(dev(np.full((1, 1, H, W), 0.75, np.float32)))[0]), 0.75, atol=1e-6)
 
 
+def test_cpp_op_craster_projection(lic):
+    """CppOp == oracle bit for bit; the window is centred, full width at the equator and narrow at the poles; a constant image stays
+    constant inside it; the mask marks it"""
+    N, Cc, H, W = 2, 3, 16, 32
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    op = lic.CppOp(True, 0, False)
+    out, mask = [host(t) for t in op.forward(dev(x))]
+    ro, rm = orc.cpp_forward(x, True)
+    assert np.array_equal(out, ro) and np.array_equal(mask, rm)
+    width = mask[0, 0].sum(1)
+    assert width[H // 2] >= W - 2 and width[0] < W / 2 and np.array_equal(width, width[::-1]) and (np.diff(width[:H // 2]) >= 0).all()
+    first = mask[0, 0].argmax(1)
+    assert (np.abs(first - (W - width - first)) <= 1).all()                    # centred to within a pixel
+    c = host(lic.CppOp(False, 0, False).forward(dev(np.full((1, 1, H, W), 0.5, np.float32)))[0])
+    assert np.allclose(c[mask[:1, :1] == 1], 0.5, atol=1e-6) and (c[mask[:1, :1] == 0] == 0).all()
+    with pytest.raises(lic.Lic360Error):
+        lic.CppOp(False, 0, False).forward(dev(np.zeros((1, 1, 8, 8), np.float32)))
+
+
+def test_viewport_op(lic):
+    """ViewportOp vs the oracle (device libm vs host libm: 1e-5 on angles and rays, 1e-4 on the sampled view), and the geometry itself:
+    the centre of the viewport looks at (theta, phi); get_viewport_xy of the current direction is the viewport centre; a direction a
+    little to the right / up lands right / up of it; a constant image stays constant"""
+    N, Cc, H, W, ho, wo, fov = 3, 2, 32, 64, 10, 14, 80.0
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    tp = np.array([[0.0, 0.0], [1.1, 0.4], [-2.3, -0.7]], np.float32)
+    op = lic.ViewportOp(fov, ho, wo, 0, False)
+    view, rays0, rota, rays, ang = [host(t) for t in op.forward(dev(x), dev(tp))]
+    rv, r0, rr, ry, ra = orc.viewport_forward(x, tp, ho, wo, np.float32(fov))
+    assert np.allclose(rays0, r0, atol=1e-6) and np.allclose(rota, rr, atol=1e-6) and np.allclose(rays, ry, atol=1e-5)
+    seam = np.abs(np.abs(ra[..., 0]) - np.pi) < 1e-3
+    assert np.allclose(ang[..., 1], ra[..., 1], atol=1e-5) and np.allclose(ang[..., 0][~seam], ra[..., 0][~seam], atol=1e-5)
+    assert np.allclose(view, rv, rtol=1e-4, atol=1e-4)
+    assert np.array_equal(host(op.cal_rota_matrix(dev(tp))), rota) and op.backward(None, None) == []
+    # geometry: the mean of the four centre pixels' rays points at (theta, phi)
+    ctr = rays[:, ho // 2 - 1:ho // 2 + 1, wo // 2 - 1:wo // 2 + 1].reshape(N, -1, 3).mean(1)
+    ctr /= np.linalg.norm(ctr, axis=1, keepdims=True)
+    want = np.stack([np.cos(tp[:, 0]) * np.cos(tp[:, 1]), np.sin(tp[:, 0]) * np.cos(tp[:, 1]), np.sin(tp[:, 1])], 1)
+    assert np.allclose(ctr, want, atol=1e-5)
+    xy = host(op.get_viewport_xy(dev(tp))[0])
+    assert np.allclose(xy, orc.viewport_xy(tp, rota, ho, wo, np.float32(fov)), atol=1e-4)
+    assert np.allclose(xy, [[wo / 2 - 0.5, ho / 2 - 0.5]] * N, atol=1e-3)
+    right_up = host(op.get_viewport_xy(dev(tp + np.array([[0.05, 0.05]], np.float32)))[0])
+    assert (right_up[:, 0] > xy[:, 0]).all() and (right_up[:, 1] < xy[:, 1]).all()
+    c = host(op.forward(dev(np.full((N, 1, H, W), -1.25, np.float32)), dev(tp))[0])
+    assert np.allclose(c, -1.25, atol=1e-6)
+
+
 def test_context_layouts(lic):
     rng = np.random.default_rng(23)
     x = rng.standard_normal((2, 12, 5, 7)).astype(np.float32)
@@ -766,8 +816,6 @@ def test_operator_extras_plain_torch(lic):
     img = torch.rand((1, 3, 512, 1024), device="cuda:0")
     v = pr(img)
     assert tuple(v.shape) == (14, 3, 171, 256) and abs(float(lo.SSIM(11, 3)(v, v.clone())) - 1.0) < 1e-5
-    with pytest.raises(NotImplementedError):
-        lic.ViewportOp(90.0, 8, 8, 0, False)
 
 
 # ------------------------------------------------------------------ encode-order conv on 16x16x4 MFMAs, direct C-ABI call
