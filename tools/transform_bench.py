@@ -54,7 +54,52 @@ def measure(batch=8, device=0, reps=3):
                      "achieved": fl / t_f / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / t_f / 1e12 / F32_PEAK_TFLOPS,
                      "algorithmic_bytes_per_launch": 2.0 * x.numel() * 4, "GBps": 2.0 * x.numel() * 4 / t_f / 1e9,
                      "torch_four_kernel_form_ms": t_t * 1e3, "speedup_vs_torch": t_t / t_f})
+    rows.append(whole_codec(enc, dec, device))
     return rows
+
+
+def whole_codec(enc, dec, device, batch=48, reps=2):
+    """image -> analysis -> both entropy encoders -> bitstreams (in HBM) -> both entropy decoders -> synthesis -> image, one stream, seeded
+    weights: the end-to-end rate of the codec on one GPU"""
+    import time
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_main_params, make_imp_params
+    from lic360_fused import FusedCodec, FusedImpCodec
+    dev = "cuda:%d" % device
+    G = 48
+    fc, ic = FusedCodec(G, 64, 128, max_batch=batch, device=device), FusedImpCodec(32, 64, max_batch=batch, device=device)
+    fc.load_layers(make_main_params(1003, G))
+    ic.load_layers(make_imp_params(1003))
+    lvl = torch.arange(G, device=dev).view(1, G, 1, 1)
+    with torch.no_grad():
+        dec.quant.weight.copy_(enc.quant.weight)
+        img = torch.rand((batch, 3, 512, 1024), device=dev)
+        chunks = [slice(i, i + 8) for i in range(0, batch, 8)]
+
+        def run():
+            parts = [enc(img[c]) for c in chunks]                           # the transforms run in sub-batches of 8 (activation memory)
+            code, mask, lv = (torch.cat([p[k] for p in parts]).contiguous() for k in range(3))
+            fc.encode_async(code, mask)
+            ic.encode_async(lv)
+            ic.decode_async(batch)
+            lv2 = ic.levels_out[:batch]
+            mask2 = (lvl < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
+            fc.decode_async(mask2, batch)
+            code2 = fc.code_out[:batch]
+            rec = torch.cat([dec(code2[c], mask2[c]) for c in chunks])
+            return code, mask, code2, rec
+        code, mask, code2, rec = run()
+        torch.cuda.synchronize()
+        exact = bool(torch.equal(code2, code * mask)) and bool(torch.isfinite(rec).all())
+        t0 = time.time()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / reps
+    return {"kernel": "whole codec: analysis + entropy encode + entropy decode + synthesis", "bound": "mfma", "images_per_launch": batch,
+            "ms_per_image": dt / batch * 1e3, "achieved": batch * 512 * 1024 / dt / 1e6, "unit": "Mpixel/s (one stream, both directions, transforms included)",
+            "peak": None, "frac": None, "roundtrip_exact": exact, "mean_latent_bytes": float(fc.nbytes[:batch].float().mean().item())}
 
 
 if __name__ == "__main__":
