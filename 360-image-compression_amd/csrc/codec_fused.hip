@@ -178,56 +178,85 @@ struct DevBitSink {
         return len;
     }
 };
-// ArithmeticEncoder::write / shift / underflow (ArithmeticCoder.cpp:34-69) on the closed forms of ac_narrow
-__device__ __forceinline__ void ac_encode_symbol_dev(AcState &s, DevBitSink &w, uint32_t symLow, uint32_t symHigh) {
-    int n1, n2;
-    uint32_t lowb;
-    ac_narrow(s, symLow, symHigh, 65536u, n1, n2, lowb);
-    if (n1) {
-        if (s.underflow == 0) w.put(lowb >> (32 - n1), n1);               // the common case: the n1 leading bits of low in one put
-        else {
-            const int bit = (int)(lowb >> 31);
-            w.put((uint32_t)bit, 1);
-            w.put_run(bit ^ 1, s.underflow);
-            s.underflow = 0;
-            if (n1 > 1) w.put(lowb >> (32 - n1), n1 - 1);                 // bits 30 .. 32-n1 of low
-        }
-    }
-    s.underflow += (uint64_t)n2;
-}
-
-// one wave per image; coder state is wave-uniform (scalar registers)
-__global__ __launch_bounds__(64) void k_ac_encode(const uint2 *__restrict__ rec, long n, uint8_t *__restrict__ bytes, long cap,
-                                                  int *__restrict__ nbytes, int *__restrict__ err) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// Two waves per image, a two-stage pipeline over groups of 64 records: wave 0 runs the interval recurrence (ac_narrow: the only part
+// that is inherently serial) and leaves, per coded symbol, the shift run n1, the underflow run n2 and the interval's low word in lane j
+// of two registers; wave 1 turns the previous group's triples into bits (ArithmeticEncoder::shift / underflow bookkeeping is a pure
+// function of that sequence).  Each wave's chain is about half of the single-wave coder's; one workgroup barrier per group.
+__global__ __launch_bounds__(128) void k_ac_encode(const uint2 *__restrict__ rec, long n, uint8_t *__restrict__ bytes, long cap,
+                                                   int *__restrict__ nbytes, int *__restrict__ err) {
+    __shared__ uint2 ring[2][64];                                         // x: low word before the shift; y: n1 | n2 << 8 | coded << 16
+    __shared__ int s_error;
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint2 *r = rec + (long)b * n;
-    AcState st;
-    ac_init(st);
-    DevBitSink bw;
-    bw.init(bytes + (long)b * cap, cap, lane);
-    // records are fetched two groups of 64 ahead of the serial chain
-    auto load_rec = [&](long base) __attribute__((always_inline)) {
-        uint2 v = make_uint2(0u, 0u);
-        if (base + lane < n) v = r[base + lane];
-        return v;
-    };
-    uint2 v = load_rec(0), v1 = load_rec(64);
-    for (long base = 0; base < n; base += 64) {
-        const uint2 v2 = load_rec(base + 128);
-        unsigned long long todo = __ballot(v.y != 0u);                    // hi == 0: not coded (mask < 0.5, coder.cpp:79)
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.x, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)v.y, j);
-            ac_encode_symbol_dev(st, bw, lo, hi);
+    const long ngroups = (n + 63) / 64;
+    if (wave == 0) {
+        AcState st;
+        ac_init(st);
+        auto load_rec = [&](long base) __attribute__((always_inline)) {
+            uint2 v = make_uint2(0u, 0u);
+            if (base + lane < n) v = r[base + lane];
+            return v;
+        };
+        uint2 v = load_rec(0), v1 = load_rec(64);                          // records are fetched two groups ahead of the chain
+        for (long g = 0; g <= ngroups; ++g) {
+            if (g < ngroups) {
+                const uint2 v2 = load_rec(64 * g + 128);
+                unsigned long long todo = __ballot(v.y != 0u);            // hi == 0: not coded (mask < 0.5, coder.cpp:79)
+                uint2 o = make_uint2(0u, 0u);
+                while (todo) {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.x, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)v.y, j);
+                    int n1, n2;
+                    uint32_t lowb;
+                    ac_narrow(st, lo, hi, 65536u, n1, n2, lowb);
+                    const uint32_t meta = (uint32_t)n1 | ((uint32_t)n2 << 8) | 0x10000u;
+                    o.x = lane == j ? lowb : o.x;
+                    o.y = lane == j ? meta : o.y;
+                }
+                ring[g & 1][lane] = o;
+                v = v1; v1 = v2;
+            }
+            __syncthreads();
         }
-        v = v1; v1 = v2;
-    }
-    bw.put(1u, 1);                                                        // ArithmeticEncoder::finish writes a single 1
-    const long len = bw.finish();
-    if (lane == 0) {
-        nbytes[b] = (int)len;
-        err[b] = st.error | (len > cap ? 16 : 0);
+        if (lane == 0) s_error = st.error;
+        __syncthreads();
+    } else {
+        DevBitSink bw;
+        bw.init(bytes + (long)b * cap, cap, lane);
+        unsigned long long underflow = 0;
+        for (long g = 0; g <= ngroups; ++g) {
+            if (g > 0) {
+                const uint2 o = ring[(g - 1) & 1][lane];
+                unsigned long long todo = __ballot((o.y >> 16) != 0u);
+                while (todo) {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint32_t lowb = (uint32_t)__builtin_amdgcn_readlane((int)o.x, j), meta = (uint32_t)__builtin_amdgcn_readlane((int)o.y, j);
+                    const int n1 = (int)(meta & 0xffu), n2 = (int)((meta >> 8) & 0xffu);
+                    if (n1) {                                               // ArithmeticCoder.cpp:53-69 on the closed forms
+                        if (underflow == 0) bw.put(lowb >> (32 - n1), n1);
+                        else {
+                            const int bit = (int)(lowb >> 31);
+                            bw.put((uint32_t)bit, 1);
+                            bw.put_run(bit ^ 1, underflow);
+                            underflow = 0;
+                            if (n1 > 1) bw.put(lowb >> (32 - n1), n1 - 1);
+                        }
+                    }
+                    underflow += (unsigned long long)n2;
+                }
+            }
+            __syncthreads();
+        }
+        bw.put(1u, 1);                                                    // ArithmeticEncoder::finish writes a single 1
+        const long len = bw.finish();
+        __syncthreads();
+        if (lane == 0) {
+            nbytes[b] = (int)len;
+            err[b] = s_error | (len > cap ? 16 : 0);
+        }
     }
 }
 
@@ -603,7 +632,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
         PROF(c, PROF_EC_LAST, s, rc |= lic360_cconv16_ec_tables(stream, c->plan[2], cur, c->packed16[11], c->bias[11], code, mask, c->d_pidx,
                                                                 c->d_plane_start, c->e_rec, B, H, W, c->e_ctr));
         if (rc) return 1;
-        PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
+        PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
         LAUNCH_CHECK();
         return 0;
     }
@@ -612,7 +641,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     PROF(c, PROF_ENC_TABLES, s, hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx,
                                                    c->d_plane_start, c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp));
     LAUNCH_CHECK();
-    PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
+    PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
     LAUNCH_CHECK();
     return 0;
 }
@@ -885,7 +914,7 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
         if (lic360_cconv144_ec(stream, c->plan[2], cur, c->packed144[11], c->bias[11], nullptr, nullptr, c->e_plain, B, H, W, (long)c->HW, W, 0)) return 1;
         hipLaunchKernelGGL(k_imp_enc_tables, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, c->e_plain, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
+        hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
         LAUNCH_CHECK();
         return 0;
     }
@@ -902,7 +931,7 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
     if (ec(11, cur, nullptr, t1)) return 1;                                         // [B, nsym, H, W] (uses the first nsym planes of the buffer)
     hipLaunchKernelGGL(k_imp_enc_tables, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, t1, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(64), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
+    hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
     LAUNCH_CHECK();
     return 0;
 }
@@ -986,7 +1015,7 @@ LIC360_API int lic360_devcoder_encode(void *stream, const int *tables, int ncode
         hipLaunchKernelGGL(k_test_records, dim3(lic360_blocks(n, 1)), dim3(256), 0, s, tables, ncode, labels, mask, n, rec);
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_ac_encode, dim3(1), dim3(64), 0, s, rec, n, bytes, cap, nbytes, err);
+    hipLaunchKernelGGL(k_ac_encode, dim3(1), dim3(128), 0, s, rec, n, bytes, cap, nbytes, err);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(rec);
