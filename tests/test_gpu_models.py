@@ -64,21 +64,21 @@ def test_blocks_match_index_only_torch(lic):
         blk = lm.ResidualBlockV2(c, 0).to("cuda:0")
         y = _trim(blk.relu1(blk.conv1(_refresh(x))), 1)
         want = x + _trim(blk.relu2(blk.conv2(y)), 2)
-        assert torch.allclose(blk(x.clone()), want, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(blk(x.clone()), want, rtol=1e-4, atol=1e-4)
         bt = lm.ResidualBlock(c, 0).to("cuda:0")
         t = _refresh(x)
         want = _trim(x + bt.conv3(bt.relu2(bt.conv2(bt.relu1(bt.conv1(t))))), 2)
-        assert torch.allclose(bt(x.clone()), want, rtol=1e-5, atol=1e-5)
+        assert torch.allclose(bt(x.clone()), want, rtol=1e-4, atol=1e-4)
         dn = lm.ResidualBlockDown(c, c, 0).to("cuda:0")
         t = _refresh(x)
         yy = _refresh(_trim(dn.relu1(dn.conv1(t)), 2))
         want = _trim(dn.short_cut(x) + dn.relu2(dn.conv2(yy)), 2)
-        assert torch.allclose(dn(x.clone()), want, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(dn(x.clone()), want, rtol=1e-4, atol=1e-4)
         up = lm.ResidualBlockUp(c, 0).to("cuda:0")
         b = _trim(F.pixel_shuffle(up.relu1(up.conv1(_refresh(x))), 2), 2)
         b = up.relu2(up.conv2(_refresh(b)))
         want = _trim(b + F.pixel_shuffle(up.short_cut(x[..., 1:-1, 1:-1]), 2), 2)
-        assert torch.allclose(up(x.clone()), want, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(up(x.clone()), want, rtol=1e-4, atol=1e-4)
 
 
 def test_state_dict_layout_is_the_references(lic):
