@@ -46,13 +46,16 @@ def test_fused_gdn_matches_torch(lic, c, inverse):
     want = torch.sqrt(F.conv2d(x * x, gamma.view(c, c, 1, 1), beta))
     want = x * want if inverse else x / want
     got = lic.gdn_forward(x, gamma, beta, inverse)
-    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), float((got - want).abs().max())
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), float((got - want).abs().max())
+    want64 = torch.sqrt(torch.einsum("ij,njhw->nihw", gamma.double(), x.double() ** 2) + beta.double().view(1, c, 1, 1))
+    want64 = x.double() * want64 if inverse else x.double() / want64
+    assert torch.allclose(got.double(), want64, rtol=2e-6, atol=1e-6)                 # against float64, no library in the loop
     import lic360_operator as lo
     m = lo.GDN(c, 0, inverse)
     with torch.no_grad():
         y_fused = m(x)
     y_torch = m(x.clone().requires_grad_(True))                             # the recording path stays on torch
-    assert torch.allclose(y_fused, y_torch.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(y_fused, y_torch.detach(), rtol=1e-4, atol=1e-5)
 
 
 def test_blocks_match_index_only_torch(lic):
