@@ -1,0 +1,20 @@
+"""single-stream decode wall time of PB images with and without the hipGraph replay of the plane sweep (LIC360_DC_GRAPH=1|0)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("360-image-compression_amd", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import torch, numpy as np
+from util import latent, make_main_params
+from lic360_fused import FusedCodec
+G, H, W, B = 48, 64, 128, int(os.environ.get("PB", 1))
+fc = FusedCodec(G, H, W, max_batch=B); fc.load_layers(make_main_params(1003, G))
+items = [latent(np.random.default_rng(i), G, H, W) for i in range(B)]
+code = torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask = torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
+st = torch.cuda.Stream()
+fc.encode_async(code, mask); torch.cuda.synchronize()
+for rep in range(4):
+    t0 = time.time()
+    with torch.cuda.stream(st):
+        fc.decode_async(mask, B)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print("B %d decode %d: %.1f ms, exact %s" % (B, rep, dt * 1e3, bool(torch.equal(fc.code_out[:B], code * mask))), flush=True)
