@@ -604,7 +604,7 @@ static int check_ready(const lic360_codec *c, int B) {
 LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *code, const float *mask, int B,
                                    uint8_t *bytes, long cap, int *nbytes, int *err) {
     if (check_ready(c, B)) return 2;
-    ARG_CHECK(code && mask && bytes && nbytes && err && cap > 0);
+    ARG_CHECK(code && mask && bytes && nbytes && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);   // DevBitSink: dword stores at bytes + b*cap
     hipStream_t s = (hipStream_t)stream;
     const int G = c->G, H = c->H, W = c->W;
     const long total = (long)B * G * c->HW;
@@ -889,7 +889,7 @@ static int imp_ready(const lic360_impcodec *c, int B) {
 }
 LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const float *levels, int B, uint8_t *bytes, long cap, int *nbytes, int *err) {
     if (imp_ready(c, B)) return 2;
-    ARG_CHECK(levels && bytes && nbytes && err && cap > 0);
+    ARG_CHECK(levels && bytes && nbytes && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
     const int H = c->H, W = c->W;
     const long total = (long)B * c->HW;
@@ -1007,7 +1007,8 @@ __global__ void k_test_tabn(const int *__restrict__ tables, int ncode, long star
 
 LIC360_API int lic360_devcoder_encode(void *stream, const int *tables, int ncode, const int *labels, const float *mask, long n,
                                       uint8_t *bytes, long cap, int *nbytes, int *err) {
-    ARG_CHECK(ncode >= 1 && n >= 0 && bytes && nbytes && err && cap > 0 && (n == 0 || (tables && labels)));
+    ARG_CHECK(ncode >= 1 && n >= 0 && bytes && nbytes && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0 &&
+              (n == 0 || (tables && labels)));
     hipStream_t s = (hipStream_t)stream;
     uint2 *rec = nullptr;
     if (dmalloc(&rec, (size_t)n)) return 1;

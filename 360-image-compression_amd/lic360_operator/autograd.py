@@ -13,14 +13,17 @@ def recording(*tensors):
 
 
 class UnaryFn(torch.autograd.Function):
-    """y = op.forward(x)[0],  dL/dx = op.backward(dL/dy)[0]; `inplace`: the op overwrites x and returns it"""
+    """y = op.forward(x)[0],  dL/dx = op.backward(dL/dy)[0]; `inplace`: the op overwrites x and returns it.
+    The in-place ops (apron refresh of SpherePad, SphereTrim) are NOT marked dirty, exactly as the reference's wrappers
+    (lic360_operator/SpherePad.py:9-15 returns the op's output, which is its input): autograd then aliases the result to x
+    and x's version counter stays put, so a convolution that saved x before the refresh can still run its backward
+    (AttentionBlock pads the same x in two branches, ResidualBlockDown pads after the shortcut has saved x).  That is sound
+    because the refresh is idempotent on everything an earlier consumer read: it rewrites apron cells with the values a
+    previous pad of the same interior already put there, and the trim's zeros are what the reference's graph sees too."""
     @staticmethod
     def forward(ctx, x, op, inplace):
         ctx.op = op
-        y = op.forward(x)[0]
-        if inplace:
-            ctx.mark_dirty(x)
-        return y
+        return op.forward(x)[0]
 
     @staticmethod
     def backward(ctx, g):

@@ -9,8 +9,45 @@ import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+
+class _Lazy:
+    """torch / torch.distributed are imported on first use: the `bench.py --gpus N` supervisor imports this module for
+    launch_ranks() and count_gpus_sysfs() only and must stay free of torch (hence of any HIP call)."""
+    def __init__(self, name):
+        self._name, self._mod = name, None
+
+    def __getattr__(self, attr):
+        if self._mod is None:
+            import importlib
+            self._mod = importlib.import_module(self._name)
+        return getattr(self._mod, attr)
+
+
+torch = _Lazy("torch")
+dist = _Lazy("torch.distributed")
+
+
+def count_gpus_sysfs(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPU agents of this machine from the KFD topology (nodes with simd_count > 0), read from sysfs: no HIP / HSA call,
+    no /dev/kfd open.  None when the topology is not there (no amdgpu driver: nothing to check against)."""
+    try:
+        nodes = sorted(os.listdir(root))
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            with open(os.path.join(root, d, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            continue
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if vis is not None and vis.strip() != "":
+        n = min(n, len([t for t in vis.split(",") if t.strip() != ""]))
+    return n
 
 
 def shard_indices(n_items, rank, world):

@@ -441,12 +441,13 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # supervisor: no HIP call in this process (device_count() does not initialise the runtime on this image)
+        # supervisor: HIP-free by construction -- it imports neither torch nor the HIP library; devices are counted from the
+        # KFD topology in sysfs (a rank whose device is missing fails in set_device and the launcher exits non-zero)
         import lic360_shard as shard
         if not args.dry_run:
-            import torch
-            if torch.cuda.device_count() < args.gpus:
-                sys.stderr.write("bench.py: --gpus %d but only %d HIP devices are visible\n" % (args.gpus, torch.cuda.device_count()))
+            have = shard.count_gpus_sysfs()
+            if have is not None and have < args.gpus:
+                sys.stderr.write("bench.py: --gpus %d but only %d GPU nodes in /sys/class/kfd\n" % (args.gpus, have))
                 return 2
         return shard.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
     return dry_run(args) if args.dry_run else run_rank(args)

@@ -26,3 +26,42 @@ def test_parameter_tree_and_flops():
     full_e, full_d = lm.EncoderV2(192, 192, 0), lm.Decoder(192, 192, 0)
     assert sum(isinstance(m, torch.nn.Conv2d) for m in full_e.modules()) == 60
     assert sum(isinstance(m, torch.nn.Conv2d) for m in full_d.modules()) == 57
+
+
+def test_inplace_sphere_ops_do_not_break_backward():
+    """UnaryFn used to mark_dirty() the in-place apron refresh / trim, which bumps x's version counter; a block that
+    pads the same x in two branches after a conv has saved it (AttentionBlock, ResidualBlockDown(hidden)) then failed in
+    backward with 'modified by an inplace operation'.  Mock op on CPU (the native op needs a GPU): the refresh is idempotent."""
+    import os
+    import sys
+    import types
+    import torch
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.modules.setdefault("lic360", types.ModuleType("lic360"))            # autograd.py itself imports nothing native
+    sys.path.insert(0, os.path.join(here, "360-image-compression_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lic360_autograd_cpu", os.path.join(here, "360-image-compression_amd", "lic360_operator", "autograd.py"))
+    ag = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ag)
+
+    class RefreshOp:                                     # in-place longitude wrap of a 1-px apron; backward = identity on this toy
+        def forward(self, x):
+            v = x.detach().numpy()                        # raw memory write, like the native op: no version-counter bump
+            v[..., 0] = v[..., -2]
+            v[..., -1] = v[..., 1]
+            return [x]
+
+        def backward(self, g):
+            return [g]
+
+    torch.manual_seed(0)
+    conv1, conv2, conv3 = (torch.nn.Conv2d(2, 2, 3, padding=1) for _ in range(3))
+    inp = torch.randn(1, 2, 6, 8, requires_grad=True)
+    x = conv1(inp)
+    op = RefreshOp()
+    x = ag.UnaryFn.apply(x, op, True)                     # the block's first pad
+    a = conv2(x)                                         # saves x
+    xb = ag.UnaryFn.apply(x, op, True)                    # the second branch pads the same x again, in place
+    b = conv3(xb)
+    (a * b).sum().backward()                             # raised before the fix
+    assert inp.grad is not None and torch.isfinite(inp.grad).all()
