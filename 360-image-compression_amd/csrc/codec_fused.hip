@@ -38,6 +38,8 @@ struct lic360_codec {
     float *packed[12], *bias[12], *act[12];
     float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
     float *packed16[12];                       // 16x16x4 MFMA weight layout of the encode-order kernel (csrc/cconv16_kernels.hip)
+    float *packed16dc[12];                     // weight layout of the decode-order 16x16x4 kernel (csrc/cconv16dc_kernels.hip), layers 1..11
+    bool use16dc = false;                      // LIC360_DC=4 keeps every decode layer on the 4x4x1 kernel (A/B runs)
     bool use4, use16, fuse_tables = true;      // fuse_tables: LIC360_EC_FUSE=0 keeps the separate table kernel (A/B runs)
     int dc_mode = 0;                           // A/B switches of the decode kernel, read from the environment once, at create
     int *e_ctr = nullptr;                      // 8 task counters of the encode kernel
@@ -492,7 +494,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     lic360_codec *c = new lic360_codec();
     memset(c->layer_set, 0, sizeof(c->layer_set));
     c->G = ngroup; c->H = h; c->W = w; c->maxB = max_batch; c->S = h + w - 1; c->P = h + w + ngroup - 2; c->HW = h * w;
-    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = c->packed16[i] = nullptr;
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = c->packed16[i] = c->packed16dc[i] = nullptr;
     int rc = 0;
     rc |= lic360_conv_plan_create(ngroup * 1, ngroup, ngroup * 4, 5, 5, &c->plan[0]);
     rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 4, 5, 6, &c->plan[1]);
@@ -530,6 +532,8 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     const int ec_mode = (force_ec4 && force_ec4[0] == '3') || (force_ec && force_ec[0] == '3') ? 3 : ((force_ec && force_ec[0] == '6') ? 6 : 16);
     c->dc_mode = lic360_dc4_env_mode();
     c->use16 = c->use4 && ec_mode == 16 && lic360_conv16_supported(c->plan[0]) && lic360_conv16_supported(c->plan[1]) && lic360_conv16_supported(c->plan[2]);
+    { const char *fd = getenv("LIC360_DC");                           // decode order, hidden + last layers: 16x16x4 MFMA kernel unless "4"
+      c->use16dc = c->use4 && h <= 64 && !(fd && fd[0] == '4') && lic360_conv16dc_supported(c->plan[1]) && lic360_conv16dc_supported(c->plan[2]); }
     if (c->use16) { if (lic360_ec16_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else if (c->use4 && w >= 7 && ec_mode != 3) {
         if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
@@ -567,7 +571,7 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
     (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab); (void)hipFree(c->e_ctr);
-    for (int i = 0; i < 12; ++i) (void)hipFree(c->packed16[i]);
+    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed16[i]); (void)hipFree(c->packed16dc[i]); }
     for (int k = 0; k < PROF_NCLS; ++k)
         for (hipEvent_t e : c->ev[k]) (void)hipEventDestroy(e);
     delete c;
@@ -584,10 +588,12 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
         if (act && dmalloc(&c->act[layer], 3 * (size_t)p->nout)) return 1;
         if (c->use4 && dmalloc(&c->packed4[layer], 3 * (size_t)lic360_conv4_packed_floats(p))) return 1;
         if (c->use16 && dmalloc(&c->packed16[layer], 3 * (size_t)lic360_conv16_packed_floats(p))) return 1;
+        if (c->use16dc && layer >= 1 && dmalloc(&c->packed16dc[layer], 3 * (size_t)lic360_conv16dc_packed_floats(p))) return 1;
     }
     if (lic360_conv_pack(stream, p, weight, 3, c->packed[layer])) return 1;
     if (c->use4 && lic360_conv4_pack(stream, p, weight, 3, c->packed4[layer])) return 1;
     if (c->use16 && lic360_conv16_pack(stream, p, weight, 3, c->packed16[layer])) return 1;
+    if (c->use16dc && layer >= 1 && lic360_conv16dc_pack(stream, p, weight, 3, c->packed16dc[layer])) return 1;
     HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->layer_set[layer] = true;
@@ -657,6 +663,10 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     const int *pih = c->h_pidx.data();
     auto dc = [&](int layer, const float *xin, const float *res, float *dst, int x_mod, int p) -> int {
         lic360_conv_plan *pl = c->plan[plan_of(layer)];
+        // hidden / last layers: the input-stationary 16x16x4 kernel, except in latency mode (few samples: the 4x4x1 kernel's
+        // one-group tasks spread a plane over more workgroups)
+        if (c->use16dc && layer >= 1 && (long)3 * B * ((G + 2) / 3) > 128)
+            return lic360_cconv16_dc_plane(stream, pl, xin, c->packed16dc[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
         if (c->use4) return lic360_cconv4_dc_plane_mode(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod, c->dc_mode);
         return lic360_cconv_dc_plane_ex(stream, pl, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3,
                                         c->d_idx, c->d_pidx, pih, p, x_mod, 1);

@@ -201,6 +201,17 @@ int lic360_conv16_pack(void *stream, const lic360_conv_plan *plan, const float *
 int lic360_cconv16_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr);
 
+/* Decode-order variant on v_mfma_f32_16x16x4_f32 (csrc/cconv16dc_kernels.hip) for the hidden / last layers of the latent nets
+ * (cin = 4, cout <= 4, h <= 64): replaces CconvDcOp.forward_act_batch / forward_batch of one plane
+ * (extension/cconv_dc_cuda.cu:313-398) on the lic360_dc4_layout activations, same results bit for bit as lic360_cconv4_dc_plane.
+ * MFMA columns = input rows of one input anti-diagonal, MFMA rows = every chain (group, channel, tap) that reads that diagonal
+ * (they all have the same length); own weight layout (lic360_conv16dc_pack). */
+int lic360_conv16dc_supported(const lic360_conv_plan *plan);
+long lic360_conv16dc_packed_floats(const lic360_conv_plan *plan);
+int lic360_conv16dc_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16dc);
+int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
+                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
+
 /* Last layer of the latent entropy model with the CDF-table build fused into its epilogue (SURVEY.md §7 k_cconv_ec_last_gmm;
  * replaces the last CconvEcBatch.forward + TileExtractBatch + EntropyBatchGmmTable.forward_batch of
  * test/lic360_demo.py:132-140, extension/entropy_gmm_table_cuda.cu:138-191): x = activations of the three stacked nets

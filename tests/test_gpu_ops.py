@@ -1001,3 +1001,69 @@ def test_cconv16_last_layer_with_fused_tables(lic, G, B, H, W):
     bad = np.argwhere((got != want).any(-1))
     assert len(bad) == 0, "%d of %d records differ, first (image, k): %s got %s want %s" % (
         len(bad), B * G * H * W, bad[:4].tolist(), got[tuple(bad[0])].tolist(), want[tuple(bad[0])].tolist())
+
+
+# ------------------------------------------------------------------ decode-order conv on 16x16x4 MFMAs (input-stationary), direct C-ABI call
+@pytest.mark.parametrize("case", [(6, 4, True, True, 3, 3, 6, 9), (48, 4, True, True, 3, 48, 8, 16), (48, 3, True, False, 3, 6, 64, 20),
+                                  (9, 4, True, True, 1, 2, 64, 9), (5, 4, False, True, 1, 1, 33, 40), (7, 4, True, True, 1, 16, 40, 12),
+                                  (4, 3, True, False, 1, 32, 30, 6), (10, 2, True, True, 2, 34, 17, 3), (48, 4, True, True, 3, 48, 64, 7)],
+                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
+def test_cconv16_dc_planes_bit_exact(lic, case):
+    """lic360_cconv16_dc_plane (hidden / last layers of the latent nets in decode order: MFMA columns = input rows of one input
+    anti-diagonal) on the lic360_dc4_layout: after every checked plane the persistent output equals the oracle's
+    (extension/cconv_dc_cuda.cu:313-398) + residual; covers one sample per task on 64 rows, two samples per task on 32 rows
+    (16 | samples per net), odd pairs, cout < 4, group counts that are no multiple of 3 or 4, odd heights, w < 5"""
+    import ctypes as C
+    G, cout, hidden, act, nb, N, H, W = case
+    rng = np.random.default_rng(1000 + 7 * G + 131 * N + 17 * H + W)
+    Cc, nout = G * 4, G * cout
+    w, b, a = conv_params(rng, nb if nb > 1 else None, nout, Cc, act=act)
+    if nb == 1:
+        w, b = w[None], b[None]
+        a = None if a is None else a[None]
+    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
+    x[rng.random(x.shape) < 0.2] = 0.0
+    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
+    constrain = 6 if hidden else 5
+    L = lic._lib
+    rows, pitch, row0, col0 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert L.lic360_dc4_layout(H, W, C.byref(rows), C.byref(pitch), C.byref(row0), C.byref(col0)) == 0
+    rows, pitch, row0, col0 = rows.value, pitch.value, row0.value, col0.value
+    th, tw = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+
+    def skew(t, fill=0.0):
+        o = np.full(t.shape[:2] + (rows, pitch), fill, np.float32)
+        o[:, :, th + tw + row0, th + col0] = t
+        return o
+
+    def to_dev(t):                                                         # planes + the slack the band fetches may touch
+        buf = torch.zeros(L.lic360_conv4_buffer_floats(0, t.shape[0] * t.shape[1], H, W), dtype=torch.float32, device="cuda:0")
+        buf[:t.size] = torch.from_numpy(t.reshape(-1)).to("cuda:0")
+        return buf
+    plan = C.c_void_p(0)
+    assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
+    assert L.lic360_conv16dc_supported(plan) == 1
+    packed = torch.empty(nb * L.lic360_conv16dc_packed_floats(plan), dtype=torch.float32, device="cuda:0")
+    wd, bd = dev(w), dev(b)
+    ad = dev(a) if act else None
+    xd, rd = to_dev(skew(x)), to_dev(skew(res))
+    out = to_dev(skew(np.zeros_like(res)))
+    s = lic._stream(0)
+    P = lic._p
+    assert L.lic360_conv16dc_pack(s, plan, P(wd), nb, P(packed)) == 0, L.lic360_last_error()
+    idx, pidx = orc.code_contex(H, W)
+    ref = np.zeros((N, nout, H, W), np.float32)
+    nplanes = H + W + G - 2
+    check = {0, 1, 2, G - 1, G, H - 1, H + 1, W, nplanes // 2, nplanes - 2, nplanes - 1}
+    # x is complete from the start (the encoder's view of the same data): the causal rule decides what a plane may read
+    for p in range(nplanes):
+        orc.cconv_dc_plane(x, w, b, a, ref, G, constrain, idx, pidx, p)
+        assert L.lic360_cconv16_dc_plane(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, p, N) == 0, L.lic360_last_error()
+        if p in check:
+            got = host(out)[:N * nout * rows * pitch].reshape(N, nout, rows, pitch)
+            g = np.arange(G).repeat(cout)[None, :, None, None]
+            on = (th + tw)[None, None] + g <= p                           # outputs of planes <= p
+            want = skew(np.where(on, ref + res, 0.0).astype(np.float32))
+            assert np.array_equal(got, want), "plane %d: %d cells differ, max abs diff %g" % (p, int((got != want).sum()), np.abs(got - want).max())
+    L.lic360_conv_plan_destroy(plan)
+    assert np.array_equal(ref, orc.cconv_ec(x, w, b, a, G, constrain))
