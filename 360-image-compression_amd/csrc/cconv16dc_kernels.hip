@@ -24,9 +24,11 @@
 //     gid = (CLS - c) mod 4 the same for every slot of a diagonal;
 //   * a workgroup = 8 waves = 4 classes x 2 row halves of one (sample, 3-group block) -- or two samples side by side when the
 //     block's diagonals fit 32 rows; 24 tiles x 2 x 4 = 192 accumulator registers per wave, two waves per SIMD;
-//   * NO LDS and NO barrier in the K loop: A (packed weights, 256 B per tile and K block) and B (8 bytes per lane) go from
-//     L2 straight to registers through a software ring; loop order = diagonal outer, K blocks inner, so a diagonal's chains
-//     run exactly their own length ceil(L/4) and nothing is padded in K beyond the last block.
+//   * NO LDS and NO barrier in the K loop: A (packed weights, one 4..16-byte load per lane for all row tiles of a diagonal)
+//     and B (8 bytes per lane) go from L2 straight to registers, 4..6 diagonals ahead of their MFMAs; loop order = K blocks
+//     outer, the LIVE diagonals of the block inner (a diagonal's chains run exactly ceil(L/4) blocks), one straight-line body
+//     per number of live diagonals -- ~5 other instructions per diagonal step: the first version of this loop spent more
+//     time issuing address arithmetic than the matrix pipe spent on the MFMAs.
 // Activations: the zero-padded diagonal-major layout of cconv4v3_dc.inc ([n][c][S+12][H+4], cell (s, th) at row s+6, col th+2).
 #include "common.h"
 #include "conv_plan.h"
@@ -38,7 +40,7 @@
 #define XD_THREADS 512
 #define XD_ROW0 6                            // == D3_S0 of cconv4v3_dc.inc (lic360_dc4_layout)
 #define XD_COL0 2
-#define XD_PMAX 4
+#define XD_R 4                               // operand slots of the K loop
 
 // ------------------------------------------------------------------------------------------------ slot tables (compile time)
 __host__ __device__ constexpr int xd_nslots(int dc) {
@@ -66,8 +68,6 @@ __host__ __device__ constexpr int xd_slot_index(int dc, int q, int kh) {
     return -1;
 }
 __host__ __device__ constexpr int xd_dc_of_tile(int tile) { int dc = 0; while (xd_tbase(dc + 1) <= tile) ++dc; return dc; }
-// ring depth of a diagonal's K loop (iterations in flight): short iterations need more of them to cover the L2 latency
-__host__ __device__ constexpr int xd_depth(int dc) { return xd_ntiles(dc) == 1 ? 4 : (xd_ntiles(dc) == 2 ? 3 : 2); }
 // halo registers published across the row halves: slots shifted towards lower rows (kh >= 3) need the partner's first column,
 // slots shifted towards higher rows (kh <= 1) its last one.  id of (dc, idx, t) in the enumeration of direction UP (1) / DOWN (0)
 __host__ __device__ constexpr bool xd_halo_has(int kh, int t, bool up) {
@@ -87,22 +87,27 @@ __host__ __device__ constexpr int xd_halo_id(int dc, int idx, int t, bool up) {
 static_assert(xd_halo_id(XD_ND, 0, 0, true) == XD_NHALO && xd_halo_id(XD_ND, 0, 0, false) == XD_NHALO, "halo registers per direction");
 
 static inline bool conv16dc_ok(const lic360_conv_plan *p) {
-    return p->ksz == 5 && p->cin == 4 && p->cout >= 1 && p->cout <= 4 && p->ngroup >= 1 && p->ngroup <= 64;
+    return p->ksz == 5 && p->cin == 4 && p->cout >= 1 && p->cout <= 4 && p->ngroup >= 4 && p->ngroup <= 64 && p->ngroup % 4 == 0;
 }
 static inline int conv16dc_ngb(const lic360_conv_plan *p) { return (p->ngroup + XD_GB - 1) / XD_GB; }
 static inline int conv16dc_nkb(const lic360_conv_plan *p) { return (p->ngroup + 3) / 4; }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// packed[net][gb][class][kb][tile][lane]: lane l = 16 k + i carries A[row i][k] of the tile's MFMA in K block kb:
+// packed[net][gb][class][kb][diagonal dc][lane][t < ntiles(dc)] (the diagonal's block starts at float tbase(dc) * 64): lane
+// l = 16 k + i carries A[row i][k] of the MFMA of tile tbase(dc) + t in K block kb -- the tiles of a diagonal side by side, so that
+// one 4..16-byte load per lane fetches a whole K step's weights (the kernel is bound by the NUMBER of vector memory instructions:
+// the CU's address unit takes ~16 cycles per wave instruction whatever its width):
 //   row i = 4 o + r, slot r of the tile = (q, kh) with kw = c + q - kh, group g = 3 gb + q, input channel 4 (4 kb + k) + gid,
 //   gid = (class - c) mod 4.  Zero where the chain has ended (tc >= L), for o >= cout, g >= G and unused slots.
 __global__ void k_conv16dc_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int G, int cout, int hidden, int n_gb, int NKB) {
     const long total = (long)nb * n_gb * 4 * NKB * XD_NT * 64;
     const int C = G * 4, nout = G * cout;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int l = (int)(e & 63);
-        long t = e >> 6;
-        const int tile = (int)(t % XD_NT); t /= XD_NT;
+        long t = e / (XD_NT * 64);
+        const int w = (int)(e - t * (XD_NT * 64));                          // position inside the (class, K block) record
+        int dcp = 0;
+        while (dcp + 1 < XD_ND && xd_tbase(dcp + 1) * 64 <= w) ++dcp;
+        const int nt = xd_ntiles(dcp), wl = w - xd_tbase(dcp) * 64, l = wl / nt, tile = xd_tbase(dcp) + wl % nt;
         const int kb = (int)(t % NKB); t /= NKB;
         const int cls = (int)(t & 3); t >>= 2;
         const int gb = (int)(t % n_gb), b = (int)(t / n_gb);
@@ -202,14 +207,22 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
     span_mask = __builtin_amdgcn_readfirstlane(span_mask);
     auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? ns_x : (ns_x + 1) >> 1; };
     int n_my = 0;
+#ifdef XD_SAMPLE_MAJOR
+    n_my = ns_x * a.n_gbv;
+#else
     for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
+#endif
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (int kt = 0;; ++kt) {
         const int u = kt * wgs_per_xcd + ((kt & 1) ? wgs_per_xcd - 1 - wg_in_xcd : wg_in_xcd);
         if (u >= n_my) break;
         int j = 0, rem = u;
+#ifdef XD_SAMPLE_MAJOR
+        { const int i = u / a.n_gbv, r = u - i * a.n_gbv; j = (r + 7 * i) % a.n_gbv; rem = i; if (rem >= units_of(j)) continue; }
+#else
         for (; j < a.n_gbv - 1 && rem >= units_of(j); ++j) rem -= units_of(j);
+#endif
         const int gb = a.gb_hi - j, tc0 = gb * XD_GB, s0 = a.psum - tc0, win = window_of(gb);
         const bool span = win < 0;
         const int T0 = span ? 0 : win;
@@ -221,15 +234,114 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
         int pe = pbase + 2 * n16;                                           // first of this lane's two input rows
         { const int pmax = (H + 1) & ~1; if (pe > pmax) pe = pmax; }         // rows >= H: the zero columns behind the image
         // operand addresses = scalar base + 32-bit lane offset (no vector address arithmetic in the K loop): lane (k, n) reads
-        // channel plane 4 (4 kb + k) + gid at rows pe, pe + 1; in the LAST K block the group index is clamped to G - 1 (only
-        // ever met by zero weights; matters when 4 does not divide G)
+        // channel plane 4 (4 kb + k) + gid at rows pe, pe + 1 (4 | G: a K block never leaves the sample's planes)
+#ifdef XD_EXP_SAMEX                                                           // ablation: every sample reads sample xcd's activations (L2-resident)
+        const char *const xs = (const char *)(a.x + (long)(xcd) * C * SKP + (long)s0 * HP + XD_COL0);
+#else
         const char *const xs = (const char *)(a.x + (long)(n_w % a.x_mod) * C * SKP + (long)s0 * HP + XD_COL0);
+#endif
         const char *const ws = (const char *)(a.packed + ((((long)net * a.ngb_all + gb) * 4 + CLS) * a.NKB) * (XD_NT * 64));
-        const unsigned offw = (unsigned)lane * 4u;
-        const unsigned offx = (unsigned)(kl * SKP4 + pe) * 4u;
-        unsigned offx_last;
-        { const int kb0 = 4 * (a.NKB - 1); int t = kb0 + kl; if (t > G - 1) t = G - 1; offx_last = (unsigned)((t - kb0) * SKP4 + pe) * 4u; }
-        // ---- epilogue operands of the waves that finish a group (class q < 3 finishes group q of its half): fetched now
+        unsigned offx[4], offw[4];                                          // per input channel gid / per tile count of a diagonal
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { offx[g] = (unsigned)((kl * 4 + g) * (int)SKP + pe) * 4u; offw[g] = (unsigned)lane * 4u * (unsigned)(g + 1); }
+        // ---- K loop: K blocks outer, the live diagonals of a block inner.  Diagonal dc is live in block kb while 4 kb < its chain
+        // length, i.e. the live ones are the prefix dc < D(kb) = min(11, X - 4 kb).  The block body exists once per D (eleven
+        // straight-line variants), so every operand load is unconditional and hipcc's wait counts are exact.  Operands live in
+        // XD_R slots, slot dc % XD_R: the MFMAs of (kb, dc) are followed by the load of the slot's next content, (kb, dc + XD_R)
+        // or (kb + 1, dc % XD_R) -- 4 to 6 diagonals (13..26 MFMAs) ahead of its use.
+        f32x4 acc[XD_NT][2];
+#pragma unroll
+        for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
+        typedef const __attribute__((address_space(1))) char *gptr;           // (explicitly global: a pointer that went through asm would be flat)
+        const int X = tc0 + 4 + a.hidden + XD_C0;                           // chain length of diagonal dc: min(G, X - dc)
+        int nKmax = ((X < G ? X : G) + 3) >> 2;
+        asm volatile("" : "+s"(nKmax));
+        const unsigned kbx = 16u * (unsigned)SKP4;                          // bytes between K blocks of x (< 2^32: one sample's planes)
+        const unsigned hp4 = (unsigned)HP * 4u;
+        auto load = [&](auto dd, XdOps &o, gptr xk, gptr wk) __attribute__((always_inline)) {
+            constexpr int dc = decltype(dd)::value, gid = (CLS - (dc - XD_C0) + 16) & 3, T = xd_ntiles(dc), tb = xd_tbase(dc);
+            gptr xb = xk + (unsigned)dc * hp4;
+            asm volatile("" : "+s"(xb));                                    // the scalar base stays scalar: global_load v, v_off, s[base]
+#ifdef XD_EXP_NOB                                                             // ablations (timing only, results are garbage)
+            if (nKmax > 1000)
+#endif
+            asm volatile("" : "+v"(offx[gid]));                             // (else hipcc widens the lane offset to 64 bits once and adds in the VALU)
+            o.b = *(const __attribute__((address_space(1))) xd_f2 *)(xb + offx[gid]);
+#ifdef XD_EXP_NOA
+            if (nKmax > 1000)
+#endif
+            {
+                typedef float xd_fT __attribute__((ext_vector_type(T == 3 ? 3 : T), aligned(T == 3 ? 4 : 4 * T)));
+                gptr wb = wk + tb * 256;
+                asm volatile("" : "+s"(wb), "+v"(offw[T - 1]));
+                if constexpr (T == 1) o.a[0] = *(const __attribute__((address_space(1))) float *)(wb + offw[0]);
+                else {
+                    const xd_fT v = *(const __attribute__((address_space(1))) xd_fT *)(wb + offw[T - 1]);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) o.a[t] = v[t];
+                }
+            }
+        };
+        auto fma = [&](auto dd, const XdOps &o) __attribute__((always_inline)) {
+            constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#ifdef XD_EXP_NOMFMA
+                acc[tb + t][0][0] += o.a[t] * o.b.x;
+#else
+                acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, acc[tb + t][0]);
+                acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, acc[tb + t][1]);
+#endif
+            }
+        };
+        XdOps slot[XD_R];
+        // full blocks (all eleven diagonals live: ~80 % of the MFMAs): one straight-line body in a plain loop
+        auto body_full = [&](gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
+            static_for<XD_ND>([&](auto dd) {
+                constexpr int dc = decltype(dd)::value, sl = dc % XD_R;
+                fma(dd, slot[sl]);
+                if constexpr (dc + XD_R < XD_ND) load(IC<dc + XD_R>{}, slot[sl], xk, wk);
+                else load(IC<sl>{}, slot[sl], xk1, wk1);                        // the next block has at least 7 live diagonals
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        // the (at most three) blocks at the end of the chains, D < 11 live diagonals, D - 4 in the block after: the same schedule
+        // under scalar conditions (each accumulator tile is written at ONE place per loop: a switch over straight-line bodies per
+        // D made hipcc spill every accumulator around every MFMA)
+        auto body_part = [&](int D, int Dn, gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
+            static_for<XD_ND - 1>([&](auto dd) {
+                constexpr int dc = decltype(dd)::value, sl = dc % XD_R;
+                if (dc < D) {
+                    fma(dd, slot[sl]);
+                    if constexpr (dc + XD_R < XD_ND - 1) { if (dc + XD_R < D) load(IC<dc + XD_R>{}, slot[sl], xk, wk); else if (sl < Dn) load(IC<sl>{}, slot[sl], xk1, wk1); }
+                    else { if (sl < Dn) load(IC<sl>{}, slot[sl], xk1, wk1); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        {
+            gptr xk = (gptr)xs, wk = (gptr)ws;
+            static_for<XD_R>([&](auto ss) { load(ss, slot[decltype(ss)::value], xk, wk); });   // (diagonals >= D(0) of a short task: harmless)
+            int nFull = X >= XD_ND ? ((X - XD_ND) >> 2) + 1 : 0;                 // blocks with X - 4 kb >= 11
+            nFull = nFull < nKmax ? nFull : nKmax;
+            asm volatile("" : "+s"(nFull));
+            int kb = 0;
+            for (; kb < nFull; ++kb) {
+                const bool more = kb + 1 < nKmax;
+                gptr xk1 = xk + (more ? kbx : 0u), wk1 = wk + (more ? (unsigned)(XD_NT * 256) : 0u);   // the very last block re-reads itself
+                asm volatile("" : "+s"(xk1), "+s"(wk1));
+                body_full(xk, xk1, wk, wk1);
+                xk = xk1; wk = wk1;
+            }
+            for (; kb < nKmax; ++kb) {
+                int D = X - 4 * kb, Dn = kb + 1 < nKmax ? D - 4 : 0;           // (chains capped at G: the last block may have D > 4 and no successor)
+                gptr xk1 = xk + kbx, wk1 = wk + (unsigned)(XD_NT * 256);       // (only dereferenced when block kb + 1 exists)
+                asm volatile("" : "+s"(xk1), "+s"(wk1), "+s"(D), "+s"(Dn));
+                body_part(D, Dn, xk, xk1, wk, wk1);
+                xk = xk1; wk = wk1;
+            }
+        }
+        // ---- epilogue operands of the waves that finish a group (class q < 3 finishes group q of its half): fetched after the K loop (they would cost 7 registers inside it), used after two barriers
         float e_bias = 0.f, e_act = 0.f;
         xd_f2 e_res = {0.f, 0.f};
         long e_oi = 0;
@@ -248,89 +360,10 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
             e_act = act_p[bid];
             e_res = *(const xd_f2 *)(res_p + (a.residual ? e_oi : 0));
         }
-        // ---- K loops: diagonal outer, K blocks inner
-        f32x4 acc[XD_NT][2];
-#pragma unroll
-        for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
-        // (the counts pass through an empty asm: left visible, hipcc correlates the eleven diagonals' trip counts and threads their
-        // branches into each other -- 100 000 branches and 20 minutes of compile time)
-        auto nk_of = [&](int dc) __attribute__((always_inline)) {
-            int L = tc0 + 4 + a.hidden - (dc - XD_C0);
-            if (L > G) L = G;
-            int nk = L > 0 ? (L + 3) >> 2 : 0;
-            asm volatile("" : "+s"(nk));
-            return nk;
-        };
-        const unsigned kbx = 16u * (unsigned)SKP4;                          // bytes between K blocks of x (< 2^32: one sample's planes)
-        auto load = [&](auto dd, XdOps &o, int kb) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, gid = (CLS - (dc - XD_C0) + 16) & 3, T = xd_ntiles(dc), tb = xd_tbase(dc);
-            typedef const __attribute__((address_space(1))) char *gptr;       // (explicitly global: a pointer that went through asm would be flat)
-            gptr xb = (gptr)(xs + ((long)dc * HP + (long)gid * SKP) * 4 + (unsigned)kb * kbx);
-            gptr wb = (gptr)(ws + ((unsigned)kb * (unsigned)(XD_NT * 256) + (unsigned)(tb * 256)));
-            asm volatile("" : "+s"(xb), "+s"(wb));                          // scalar bases stay scalar: global_load v, v_off, s[base]
-            o.b = *(const __attribute__((address_space(1))) xd_f2 *)(xb + (kb == a.NKB - 1 ? offx_last : offx));
-#pragma unroll
-            for (int t = 0; t < T; ++t) o.a[t] = *(const __attribute__((address_space(1))) float *)((wb + t * 256) + offw);
-        };
-        auto fma = [&](auto dd, const XdOps &o) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, acc[tb + t][0]);
-                acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, acc[tb + t][1]);
-            }
-        };
-        // three rings: a diagonal's trailing (clamped) reloads are still in flight when the next diagonal starts, and refilling
-        // THEIR registers for the diagonal after it would make hipcc wait for them
-        XdOps ringA[XD_PMAX], ringB[XD_PMAX], ringC[XD_PMAX];
-        auto prologue = [&](auto dd, XdOps(&ring)[XD_PMAX], int nK) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, P = xd_depth(dc);
-            static_for<P>([&](auto rr) { constexpr int r = decltype(rr)::value; load(dd, ring[r], r < nK ? r : (nK > 0 ? nK - 1 : 0)); });
-        };
-        auto run = [&](auto dd, XdOps(&ring)[XD_PMAX], int nK) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, P = xd_depth(dc);
-            int i = 0;
-            if (nK >= P) {
-                // first group peeled: the next diagonal's prologue loads are still in flight here, and a wait count merged with
-                // the loop's back edge would make the wave wait for them
-                static_for<P>([&](auto rr) {
-                    constexpr int r = decltype(rr)::value;
-                    fma(dd, ring[r]);
-                    const int nx = P + r;
-                    load(dd, ring[r], nx < nK ? nx : nK - 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                for (i = P; i + P <= nK; i += P) {
-                    static_for<P>([&](auto rr) {
-                        constexpr int r = decltype(rr)::value;
-                        fma(dd, ring[r]);
-                        const int nx = i + P + r;
-                        load(dd, ring[r], nx < nK ? nx : nK - 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                }
-            }
-            const int left = nK - i;
-            static_for<P - 1>([&](auto rr) {
-                constexpr int r = decltype(rr)::value;
-                if (r < left) fma(dd, ring[r]);
-            });
-        };
-        auto with_ring = [&](auto rr, auto &&f) __attribute__((always_inline)) {
-            constexpr int r = decltype(rr)::value % 3;
-            if constexpr (r == 0) f(ringA); else if constexpr (r == 1) f(ringB); else f(ringC);
-        };
-        prologue(IC<0>{}, ringA, nk_of(0));
-        static_for<XD_ND>([&](auto dd) {
-            constexpr int dc = decltype(dd)::value;
-            const int nK = nk_of(dc);
-            if constexpr (dc + 1 < XD_ND) {                                 // (a dead diagonal's prologue re-reads K block 0: harmless)
-                const int nKn = nk_of(dc + 1);
-                with_ring(IC<dc + 1>{}, [&](auto &ring) __attribute__((always_inline)) { prologue(IC<dc + 1>{}, ring, nKn); });
-            }
-            with_ring(dd, [&](auto &ring) __attribute__((always_inline)) { run(dd, ring, nK); });
-            __builtin_amdgcn_sched_barrier(0);
-        });
+#ifdef XD_EXP_NOEPI
+        if (a.N < 0)
+#endif
+        {
         // ---- halo: the partner half's edge column of every shifted slot (only when the two halves are one sample)
         if (span) {
             if (half == 1) {
@@ -417,6 +450,10 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
             else if (e_ok0) a.out[e_oi] = sv[0];
             else if (e_ok1) a.out[e_oi + 1] = sv[1];
         }
+        }
+#ifdef XD_EXP_NOEPI
+        if (acc[0][0][0] == 1.2345f && acc[23][1][3] == 5.f) a.out[0] = acc[5][0][1] + acc[11][1][2] + acc[17][0][0];   // keep the K loops alive
+#endif
     }
 }
 
@@ -425,6 +462,9 @@ __global__ __launch_bounds__(XD_THREADS, 2) void k_cconv16dc(XdArgs a) {
     __shared__ float comb[XD_GB * 2 * 4 * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cls = wave & 3, half = wave >> 2;
+#ifdef XD_EXP_EMPTY
+    if (a.N > 0) return;
+#endif
 #ifdef XD_ONE_CLASS
     (void)cls;
     xd_body<1>(a, halo, comb, lane, half);

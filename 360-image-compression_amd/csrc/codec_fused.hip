@@ -532,8 +532,8 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     const int ec_mode = (force_ec4 && force_ec4[0] == '3') || (force_ec && force_ec[0] == '3') ? 3 : ((force_ec && force_ec[0] == '6') ? 6 : 16);
     c->dc_mode = lic360_dc4_env_mode();
     c->use16 = c->use4 && ec_mode == 16 && lic360_conv16_supported(c->plan[0]) && lic360_conv16_supported(c->plan[1]) && lic360_conv16_supported(c->plan[2]);
-    { const char *fd = getenv("LIC360_DC");                           // decode order, hidden + last layers: 16x16x4 MFMA kernel unless "4"
-      c->use16dc = c->use4 && h <= 64 && !(fd && fd[0] == '4') && lic360_conv16dc_supported(c->plan[1]) && lic360_conv16dc_supported(c->plan[2]); }
+    { const char *fd = getenv("LIC360_DC");                           // decode order, hidden + last layers: "16" = the 16x16x4 MFMA kernel
+      c->use16dc = c->use4 && h <= 64 && (fd && fd[0] == '1' && fd[1] == '6') && lic360_conv16dc_supported(c->plan[1]) && lic360_conv16dc_supported(c->plan[2]); }
     if (c->use16) { if (lic360_ec16_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else if (c->use4 && w >= 7 && ec_mode != 3) {
         if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
