@@ -40,7 +40,12 @@
 #define XD_THREADS 512
 #define XD_ROW0 6                            // == D3_S0 of cconv4v3_dc.inc (lic360_dc4_layout)
 #define XD_COL0 2
-#define XD_R 4                               // operand slots of the K loop
+#ifndef XD_RA
+#define XD_RA 4                              // weight operand slots of the K loop (L2-resident data)
+#endif
+#ifndef XD_RB
+#define XD_RB 4                              // activation operand slots (deeper rings were measured: no gain)
+#endif
 
 // ------------------------------------------------------------------------------------------------ slot tables (compile time)
 __host__ __device__ constexpr int xd_nslots(int dc) {
@@ -158,7 +163,7 @@ __device__ __forceinline__ float xd_row_shift(float edge, float v) {     // lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
-struct XdOps { xd_f2 b; float a[4]; };
+struct XdOps { float a[4]; };
 
 // reference tree over the leaves of group Q's class CQ: F(i, 128) = leaf i, F(i, s) = F(i, 2s) + F(i + s, 2s), result F(CQ, 4)
 template <int I, int S>
@@ -177,6 +182,19 @@ struct XdTree<I, 128> {
     template <class F>
     static __device__ __forceinline__ float eval(F &&leaf) { return leaf(IC<I>{}); }
 };
+
+#ifdef XD_STAMP
+// diagnostic build only: cycles per phase, summed per wave over the launch (no product code reads these)
+__device__ unsigned long long xd_stamps[256 * 8 * 8];
+#define XD_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[i] += t_ - t0; t0 = t_; } while (0)
+LIC360_API int lic360_xd_stamps(unsigned long long *host_out, int clear) {
+    if (host_out) HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(xd_stamps), sizeof(xd_stamps)));
+    if (clear) { static unsigned long long z[256 * 8 * 8]; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(xd_stamps), z, sizeof(z))); }
+    return 0;
+}
+#else
+#define XD_T(i)
+#endif
 
 template <int CLS>
 __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *comb, const int lane, const int half) {
@@ -207,73 +225,82 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
     span_mask = __builtin_amdgcn_readfirstlane(span_mask);
     auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? ns_x : (ns_x + 1) >> 1; };
     int n_my = 0;
-#ifdef XD_SAMPLE_MAJOR
-    n_my = ns_x * a.n_gbv;
-#else
     for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
-#endif
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0;; ++kt) {
+#ifdef XD_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- task descriptors.  The walk is software-pipelined: task k + 1 is decoded and its first operand loads are issued BEFORE
+    // the epilogue of task k (the operand slots are free then), so no task starts by waiting for memory.
+    struct Task {
+        int tc0, s0, n_w, net, pbase, X, nKmax;
+        bool span, valid_w;
+        const char *xs, *ws;
+    };
+    int scan_j = 0, scan_base = 0;                                          // block of the walk's current task and its first task index
+    auto decode = [&](int kt, Task &t) __attribute__((always_inline)) {
         const int u = kt * wgs_per_xcd + ((kt & 1) ? wgs_per_xcd - 1 - wg_in_xcd : wg_in_xcd);
-        if (u >= n_my) break;
-        int j = 0, rem = u;
-#ifdef XD_SAMPLE_MAJOR
-        { const int i = u / a.n_gbv, r = u - i * a.n_gbv; j = (r + 7 * i) % a.n_gbv; rem = i; if (rem >= units_of(j)) continue; }
-#else
-        for (; j < a.n_gbv - 1 && rem >= units_of(j); ++j) rem -= units_of(j);
-#endif
-        const int gb = a.gb_hi - j, tc0 = gb * XD_GB, s0 = a.psum - tc0, win = window_of(gb);
-        const bool span = win < 0;
-        const int T0 = span ? 0 : win;
-        int n_w = span ? xcd + 8 * rem : xcd + 16 * rem + 8 * half;
-        const bool valid_w = n_w < a.N;
-        if (!valid_w) n_w = xcd + 16 * rem;                                 // the idle half of an odd pair recomputes sample A and stores nothing
-        const int net = n_w / a.npb;
-        const int pbase = T0 + (span ? 32 * half : 0);
-        int pe = pbase + 2 * n16;                                           // first of this lane's two input rows
-        { const int pmax = (H + 1) & ~1; if (pe > pmax) pe = pmax; }         // rows >= H: the zero columns behind the image
-        // operand addresses = scalar base + 32-bit lane offset (no vector address arithmetic in the K loop): lane (k, n) reads
-        // channel plane 4 (4 kb + k) + gid at rows pe, pe + 1 (4 | G: a K block never leaves the sample's planes)
+        if (u >= n_my) return false;
+        while (scan_j < a.n_gbv - 1 && u >= scan_base + units_of(scan_j)) { scan_base += units_of(scan_j); ++scan_j; }   // (u grows with kt)
+        const int rem = u - scan_base, gb = a.gb_hi - scan_j;
+        t.span = (span_mask >> scan_j) & 1u;
+        t.tc0 = gb * XD_GB; t.s0 = a.psum - t.tc0;
+        const int T0 = t.span ? 0 : window_of(gb);
+        int n_w = t.span ? xcd + 8 * rem : xcd + 16 * rem + 8 * half;
+        t.valid_w = n_w < a.N;
+        if (!t.valid_w) n_w = xcd + 16 * rem;                               // the idle half of an odd pair recomputes sample A and stores nothing
+        t.n_w = n_w;
+        int net = 0;                                                        // n_w / npb without a division (few stacked nets)
+        for (int q = a.npb; q <= n_w; q += a.npb) ++net;
+        t.net = net;
+        t.pbase = T0 + (t.span ? 32 * half : 0);
+        t.X = t.tc0 + 4 + a.hidden + XD_C0;                                 // chain length of diagonal dc: min(G, X - dc)
+        t.nKmax = ((t.X < G ? t.X : G) + 3) >> 2;
 #ifdef XD_EXP_SAMEX                                                           // ablation: every sample reads sample xcd's activations (L2-resident)
-        const char *const xs = (const char *)(a.x + (long)(xcd) * C * SKP + (long)s0 * HP + XD_COL0);
+        t.xs = (const char *)(a.x + (long)(xcd) * C * SKP + (long)t.s0 * HP + XD_COL0);
 #else
-        const char *const xs = (const char *)(a.x + (long)(n_w % a.x_mod) * C * SKP + (long)s0 * HP + XD_COL0);
+        t.xs = (const char *)(a.x + (long)(n_w < a.x_mod ? n_w : n_w % a.x_mod) * C * SKP + (long)t.s0 * HP + XD_COL0);
 #endif
-        const char *const ws = (const char *)(a.packed + ((((long)net * a.ngb_all + gb) * 4 + CLS) * a.NKB) * (XD_NT * 64));
-        unsigned offx[4], offw[4];                                          // per input channel gid / per tile count of a diagonal
+        t.ws = (const char *)(a.packed + ((((long)net * a.ngb_all + gb) * 4 + CLS) * a.NKB) * (XD_NT * 64));
+        return true;
+    };
+    // operand addresses = scalar base + 32-bit lane offset (no vector address arithmetic in the K loop): lane (k, n) reads channel
+    // plane 4 (4 kb + k) + gid at rows pe, pe + 1 (4 | G: a K block never leaves the sample's planes)
+    unsigned offx[4], offw[4];                                              // per input channel gid / per tile count of a diagonal
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { offx[g] = (unsigned)((kl * 4 + g) * (int)SKP + pe) * 4u; offw[g] = (unsigned)lane * 4u * (unsigned)(g + 1); }
-        // ---- K loop: K blocks outer, the live diagonals of a block inner.  Diagonal dc is live in block kb while 4 kb < its chain
-        // length, i.e. the live ones are the prefix dc < D(kb) = min(11, X - 4 kb).  The block body exists once per D (eleven
-        // straight-line variants), so every operand load is unconditional and hipcc's wait counts are exact.  Operands live in
-        // XD_R slots, slot dc % XD_R: the MFMAs of (kb, dc) are followed by the load of the slot's next content, (kb, dc + XD_R)
-        // or (kb + 1, dc % XD_R) -- 4 to 6 diagonals (13..26 MFMAs) ahead of its use.
-        f32x4 acc[XD_NT][2];
+    for (int g = 0; g < 4; ++g) offw[g] = (unsigned)lane * 4u * (unsigned)(g + 1);
+    int pe = 0;                                                             // first of this lane's two input rows
+    auto lane_rows = [&](const Task &t) __attribute__((always_inline)) {
+        pe = t.pbase + 2 * n16;
+        { const int pmax = (H + 1) & ~1; if (pe > pmax) pe = pmax; }         // rows >= H: the zero columns behind the image
 #pragma unroll
-        for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
-        typedef const __attribute__((address_space(1))) char *gptr;           // (explicitly global: a pointer that went through asm would be flat)
-        const int X = tc0 + 4 + a.hidden + XD_C0;                           // chain length of diagonal dc: min(G, X - dc)
-        int nKmax = ((X < G ? X : G) + 3) >> 2;
-        asm volatile("" : "+s"(nKmax));
-        const unsigned kbx = 16u * (unsigned)SKP4;                          // bytes between K blocks of x (< 2^32: one sample's planes)
-        const unsigned hp4 = (unsigned)HP * 4u;
-        auto load = [&](auto dd, XdOps &o, gptr xk, gptr wk) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, gid = (CLS - (dc - XD_C0) + 16) & 3, T = xd_ntiles(dc), tb = xd_tbase(dc);
+        for (int g = 0; g < 4; ++g) offx[g] = (unsigned)((kl * 4 + g) * (int)SKP + pe) * 4u;
+    };
+    typedef const __attribute__((address_space(1))) char *gptr;               // (explicitly global: a pointer that went through asm would be flat)
+    const unsigned kbx = 16u * (unsigned)SKP4;                              // bytes between K blocks of x (< 2^32: one sample's planes)
+    const unsigned hp4 = (unsigned)HP * 4u;
+    f32x4 acc[XD_NT][2];
+    // ---- K loop machinery: K blocks outer, the live diagonals of a block inner.  Diagonal dc is live in block kb while 4 kb < its
+    // chain length, i.e. the live ones are the prefix dc < D(kb) = min(11, X - 4 kb).
+        auto loadB = [&](auto dd, xd_f2 &b, gptr xk) __attribute__((always_inline)) {
+            constexpr int dc = decltype(dd)::value, gid = (CLS - (dc - XD_C0) + 16) & 3;
             gptr xb = xk + (unsigned)dc * hp4;
-            asm volatile("" : "+s"(xb));                                    // the scalar base stays scalar: global_load v, v_off, s[base]
+            asm volatile("" : "+s"(xb), "+v"(offx[gid]));                   // scalar base + 32-bit lane offset: global_load v, v_off, s[base]
 #ifdef XD_EXP_NOB                                                             // ablations (timing only, results are garbage)
-            if (nKmax > 1000)
+            if (a.N < 0)
 #endif
-            asm volatile("" : "+v"(offx[gid]));                             // (else hipcc widens the lane offset to 64 bits once and adds in the VALU)
-            o.b = *(const __attribute__((address_space(1))) xd_f2 *)(xb + offx[gid]);
+            b = *(const __attribute__((address_space(1))) xd_f2 *)(xb + offx[gid]);
+        };
+        auto loadA = [&](auto dd, XdOps &o, gptr wk) __attribute__((always_inline)) {
+            constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
+            typedef float xd_fT __attribute__((ext_vector_type(T == 3 ? 3 : T), aligned(T == 3 ? 4 : 4 * T)));
+            gptr wb = wk + tb * 256;
+            asm volatile("" : "+s"(wb), "+v"(offw[T - 1]));                 // (else hipcc widens the lane offset to 64 bits once and adds in the VALU)
 #ifdef XD_EXP_NOA
-            if (nKmax > 1000)
+            if (a.N < 0)
 #endif
             {
-                typedef float xd_fT __attribute__((ext_vector_type(T == 3 ? 3 : T), aligned(T == 3 ? 4 : 4 * T)));
-                gptr wb = wk + tb * 256;
-                asm volatile("" : "+s"(wb), "+v"(offw[T - 1]));
                 if constexpr (T == 1) o.a[0] = *(const __attribute__((address_space(1))) float *)(wb + offw[0]);
                 else {
                     const xd_fT v = *(const __attribute__((address_space(1))) xd_fT *)(wb + offw[T - 1]);
@@ -282,65 +309,82 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
                 }
             }
         };
-        auto fma = [&](auto dd, const XdOps &o) __attribute__((always_inline)) {
+        auto fma = [&](auto dd, const XdOps &o, const xd_f2 &b) __attribute__((always_inline)) {
             constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
 #ifdef XD_EXP_NOMFMA
-                acc[tb + t][0][0] += o.a[t] * o.b.x;
+                acc[tb + t][0][0] += o.a[t] * b.x;
 #else
-                acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, acc[tb + t][0]);
-                acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, acc[tb + t][1]);
+                acc[tb + t][0] = xd_mfma(o.a[t], b.x, acc[tb + t][0]);
+                acc[tb + t][1] = xd_mfma(o.a[t], b.y, acc[tb + t][1]);
 #endif
             }
         };
-        XdOps slot[XD_R];
-        // full blocks (all eleven diagonals live: ~80 % of the MFMAs): one straight-line body in a plain loop
-        auto body_full = [&](gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
-            static_for<XD_ND>([&](auto dd) {
-                constexpr int dc = decltype(dd)::value, sl = dc % XD_R;
-                fma(dd, slot[sl]);
-                if constexpr (dc + XD_R < XD_ND) load(IC<dc + XD_R>{}, slot[sl], xk, wk);
-                else load(IC<sl>{}, slot[sl], xk1, wk1);                        // the next block has at least 7 live diagonals
+        // operand slots: weights of diagonal dc in sa[dc % XD_RA], activations in sb[dc % XD_RB]; after the MFMAs of (kb, dc) a slot is
+        // refilled with its next content, (kb, dc + R) or (kb + 1, dc % R): activations (may miss every cache) run further ahead
+        XdOps sa[XD_RA];
+        xd_f2 sb[XD_RB];
+        // Three straight-line block bodies, for up to 11, 7 and 3 live diagonals: every load is unconditional, so hipcc's wait counts
+        // are exact.  A block with D live diagonals runs in the smallest body >= D; a dead diagonal inside it multiplies zero weights
+        // (the packed array is zero past a chain's end) with whatever its rows hold: exact, ~5 % more MFMAs.  Since D drops by 4 per
+        // block, a task is [body 11]* [body 7]? [body 3]?  (Scalar conditions per diagonal instead: every step waited for ALL loads.
+        // A switch over eleven bodies: hipcc spilled every accumulator around every MFMA.)
+        auto body = [&](auto NN, auto NX, gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
+            constexpr int N = decltype(NN)::value, NEXT = decltype(NX)::value;   // NEXT: diagonals the following block's body runs
+            constexpr int NA = NEXT < XD_RA ? NEXT : XD_RA, NB = NEXT < XD_RB ? NEXT : XD_RB;     // slots it expects filled
+            static_for<N>([&](auto dd) {
+                constexpr int dc = decltype(dd)::value, la = dc % XD_RA, lb = dc % XD_RB;
+                fma(dd, sa[la], sb[lb]);
+                if constexpr (dc + XD_RB < N) loadB(IC<dc + XD_RB>{}, sb[lb], xk); else if constexpr (lb < NB) loadB(IC<lb>{}, sb[lb], xk1);
+                if constexpr (dc + XD_RA < N) loadA(IC<dc + XD_RA>{}, sa[la], wk); else if constexpr (la < NA) loadA(IC<la>{}, sa[la], wk1);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
-        // the (at most three) blocks at the end of the chains, D < 11 live diagonals, D - 4 in the block after: the same schedule
-        // under scalar conditions (each accumulator tile is written at ONE place per loop: a switch over straight-line bodies per
-        // D made hipcc spill every accumulator around every MFMA)
-        auto body_part = [&](int D, int Dn, gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
-            static_for<XD_ND - 1>([&](auto dd) {
-                constexpr int dc = decltype(dd)::value, sl = dc % XD_R;
-                if (dc < D) {
-                    fma(dd, slot[sl]);
-                    if constexpr (dc + XD_R < XD_ND - 1) { if (dc + XD_R < D) load(IC<dc + XD_R>{}, slot[sl], xk, wk); else if (sl < Dn) load(IC<sl>{}, slot[sl], xk1, wk1); }
-                    else { if (sl < Dn) load(IC<sl>{}, slot[sl], xk1, wk1); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
+        auto fill = [&](const Task &t) __attribute__((always_inline)) {       // operands of block 0, the first diagonals (rows always exist)
+            static_for<XD_RB>([&](auto ss) { loadB(ss, sb[decltype(ss)::value], (gptr)t.xs); });
+            static_for<XD_RA>([&](auto ss) { loadA(ss, sa[decltype(ss)::value], (gptr)t.ws); });
         };
+    Task cur, nxt;
+    if (!decode(0, cur)) return;                                            // (uniform over the workgroup)
+    lane_rows(cur);
+    fill(cur);
+    for (int kt = 0;; ++kt) {
+        const int tc0 = cur.tc0, s0 = cur.s0, n_w = cur.n_w, net = cur.net, pbase = cur.pbase;
+        const bool span = cur.span, valid_w = cur.valid_w;
+#pragma unroll
+        for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
+        XD_T(0);
         {
-            gptr xk = (gptr)xs, wk = (gptr)ws;
-            static_for<XD_R>([&](auto ss) { load(ss, slot[decltype(ss)::value], xk, wk); });   // (diagonals >= D(0) of a short task: harmless)
-            int nFull = X >= XD_ND ? ((X - XD_ND) >> 2) + 1 : 0;                 // blocks with X - 4 kb >= 11
-            nFull = nFull < nKmax ? nFull : nKmax;
-            asm volatile("" : "+s"(nFull));
-            int kb = 0;
-            for (; kb < nFull; ++kb) {
-                const bool more = kb + 1 < nKmax;
-                gptr xk1 = xk + (more ? kbx : 0u), wk1 = wk + (more ? (unsigned)(XD_NT * 256) : 0u);   // the very last block re-reads itself
+            gptr xk = (gptr)cur.xs, wk = (gptr)cur.ws;
+            const int X = cur.X;
+            int nKmax = cur.nKmax;
+            asm volatile("" : "+s"(nKmax));
+            int kb = 0, D = X;                                                  // live diagonals of block kb (uncapped)
+            auto next_ptrs = [&](gptr &xk1, gptr &wk1) __attribute__((always_inline)) {
+                const bool more = kb + 1 < nKmax;                               // the task's last block re-reads itself
+                xk1 = xk + (more ? kbx : 0u); wk1 = wk + (more ? (unsigned)(XD_NT * 256) : 0u);
                 asm volatile("" : "+s"(xk1), "+s"(wk1));
-                body_full(xk, xk1, wk, wk1);
+            };
+            for (; kb < nKmax && D >= 8; ++kb, D -= 4) {
+                gptr xk1, wk1;
+                next_ptrs(xk1, wk1);
+                body(IC<XD_ND>{}, IC<XD_ND>{}, xk, xk1, wk, wk1);                // next: body 11 or 7 (a dead diagonal's operands: harmless)
                 xk = xk1; wk = wk1;
             }
-            for (; kb < nKmax; ++kb) {
-                int D = X - 4 * kb, Dn = kb + 1 < nKmax ? D - 4 : 0;           // (chains capped at G: the last block may have D > 4 and no successor)
-                gptr xk1 = xk + kbx, wk1 = wk + (unsigned)(XD_NT * 256);       // (only dereferenced when block kb + 1 exists)
-                asm volatile("" : "+s"(xk1), "+s"(wk1), "+s"(D), "+s"(Dn));
-                body_part(D, Dn, xk, xk1, wk, wk1);
-                xk = xk1; wk = wk1;
+            if (kb < nKmax && D >= 4) {
+                gptr xk1, wk1;
+                next_ptrs(xk1, wk1);
+                body(IC<7>{}, IC<3>{}, xk, xk1, wk, wk1);
+                xk = xk1; wk = wk1; ++kb; D -= 4;
             }
+            if (kb < nKmax) body(IC<3>{}, IC<0>{}, xk, xk, wk, wk);
         }
+        XD_T(1);
+        // ---- the next task: decode, lane offsets, first operand loads (in flight during this task's epilogue)
+        const int pe_e = pe;                                                // this task's rows, for the epilogue
+        const bool have_next = decode(kt + 1, nxt);
+        if (have_next) { lane_rows(nxt); fill(nxt); }
         // ---- epilogue operands of the waves that finish a group (class q < 3 finishes group q of its half): fetched after the K loop (they would cost 7 registers inside it), used after two barriers
         float e_bias = 0.f, e_act = 0.f;
         xd_f2 e_res = {0.f, 0.f};
@@ -355,7 +399,7 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
             e_ok1 = vq && p0 + 1 >= lo && p0 + 1 <= hi;
             const int gc = g < G ? g : G - 1, oc = o < a.cout ? o : a.cout - 1, sc = sq < 0 ? 0 : (sq >= S ? S - 1 : sq);
             const int bid = net * nout + gc * a.cout + oc;
-            e_oi = ((long)n_w * nout + gc * a.cout + oc) * SKP + (long)(sc + XD_ROW0) * HP + pe + XD_COL0;
+            e_oi = ((long)n_w * nout + gc * a.cout + oc) * SKP + (long)(sc + XD_ROW0) * HP + pe_e + XD_COL0;
             e_bias = a.bias[bid];
             e_act = act_p[bid];
             e_res = *(const xd_f2 *)(res_p + (a.residual ? e_oi : 0));
@@ -400,11 +444,14 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
                 }
             }
         }
+        XD_T(2);
         __syncthreads();
+        XD_T(3);
         // ---- realignment + the reference tree inside the class, per group and output row tile
         // this wave has a partner above / below: its edge columns come from the halo (all ones), else they are zeros
-        int up_mask = __builtin_amdgcn_readfirstlane((span && half == 0) ? -1 : 0), dn_mask = __builtin_amdgcn_readfirstlane((span && half == 1) ? -1 : 0);
-        asm volatile("" : "+s"(up_mask), "+s"(dn_mask));
+        // (a wave without a partner reads the block of zeros instead: one address select per task, not one AND per register)
+        const float *const halo_up = halo + ((span && half == 0) ? (1 * 4 + CLS) * XD_NHALO * 4 : 2 * 4 * XD_NHALO * 4) + kl;
+        const float *const halo_dn = halo + ((span && half == 1) ? (0 * 4 + CLS) * XD_NHALO * 4 : 2 * 4 * XD_NHALO * 4) + kl;
         static_for<XD_GB>([&](auto qq) {
             constexpr int Q = decltype(qq)::value, CQ = (CLS + Q) & 3;
             static_for<2>([&](auto tt) {
@@ -419,12 +466,12 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
                     else if constexpr (dl == 1 && TP == 0) return acc[tile][1][reg];
                     else if constexpr (dl == -1 && TP == 1) return acc[tile][0][reg];
                     else if constexpr (dl > 0) {                              // needs column n + 1 of source tile TS
-                        constexpr int TS = dl == 1 ? 0 : TP, hid = ((1 * 4 + CLS) * XD_NHALO + xd_halo_id(dc, idx, TS, true)) * 4;
-                        const float e = __builtin_bit_cast(float, __builtin_bit_cast(int, halo[hid + kl]) & up_mask);
+                        constexpr int TS = dl == 1 ? 0 : TP, hid = xd_halo_id(dc, idx, TS, true) * 4;
+                        const float e = halo_up[hid];
                         return xd_row_shift<XD_ROW_SHL1>(e, acc[tile][TS][reg]);
                     } else {                                                  // column n - 1
-                        constexpr int TS = dl == -1 ? 1 : TP, hid = ((0 * 4 + CLS) * XD_NHALO + xd_halo_id(dc, idx, TS, false)) * 4;
-                        const float e = __builtin_bit_cast(float, __builtin_bit_cast(int, halo[hid + kl]) & dn_mask);
+                        constexpr int TS = dl == -1 ? 1 : TP, hid = xd_halo_id(dc, idx, TS, false) * 4;
+                        const float e = halo_dn[hid];
                         return xd_row_shift<XD_ROW_SHR1>(e, acc[tile][TS][reg]);
                     }
                 };
@@ -432,7 +479,9 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
                 comb[((((Q * 2 + TP) * 4 + CQ) * 2 + half) * 64) + lane] = part;
             });
         });
+        XD_T(4);
         __syncthreads();
+        XD_T(5);
         // ---- last two tree levels across the classes + bias / PReLU / residual / store: class q finishes group q of its half
         if constexpr (CLS < XD_GB) {
             constexpr int Q = CLS;
@@ -451,14 +500,25 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
             else if (e_ok1) a.out[e_oi + 1] = sv[1];
         }
         }
+        XD_T(6);
+        if (!have_next) break;
+        cur = nxt;
 #ifdef XD_EXP_NOEPI
         if (acc[0][0][0] == 1.2345f && acc[23][1][3] == 5.f) a.out[0] = acc[5][0][1] + acc[11][1][2] + acc[17][0][0];   // keep the K loops alive
 #endif
     }
+#ifdef XD_STAMP
+    if (lane == 0) {
+        st[7] += __builtin_amdgcn_s_memtime() - t0;
+        for (int i = 0; i < 8; ++i) xd_stamps[(blockIdx.x * 8 + half * 4 + CLS) * 8 + i] += st[i];
+    }
+#endif
 }
 
 __global__ __launch_bounds__(XD_THREADS, 2) void k_cconv16dc(XdArgs a) {
-    __shared__ float halo[2 * 4 * XD_NHALO * 4];
+    __shared__ float halo[(2 * 4 + 1) * XD_NHALO * 4];                      // [direction][class][register][channel] + a block of zeros
+    for (int i = threadIdx.x; i < XD_NHALO * 4; i += XD_THREADS) halo[2 * 4 * XD_NHALO * 4 + i] = 0.f;
+    __syncthreads();
     __shared__ float comb[XD_GB * 2 * 4 * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cls = wave & 3, half = wave >> 2;
