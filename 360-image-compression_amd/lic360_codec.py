@@ -68,9 +68,41 @@ def init_entropy_network(m, p1, p2):
 
 
 class _Driver(torch.nn.Module):
+    """Shared plumbing of the four plane-sweep drivers.  A driver owns `ctx` (scan order), `net` (the context model), the plane
+    gather ops and `mcoder`; its forward() is one sweep over the P = h + w + ngroup - 2 anti-diagonal planes.  Constructor
+    signatures and sub-module names are the reference's (they fix the state-dict layout, test/lic360_demo.py:95-290); the sweeps
+    are written against the helpers below."""
+    cuda_name = "cuda:0"
+
     def _begin(self, ref_tensor):
         self.p1, self.p2 = self.ctx(ref_tensor)
         self.apply(lambda m: init_entropy_network(m, self.p1, self.p2))
+
+    def _planes(self, h, w):
+        return h + w + self.ngroup - 2
+
+    def _open(self, code_name, decode):
+        """stateful plane ops back to plane 0, coder onto `code_name`"""
+        self.apply(restart_entropy_network)
+        self.mcoder.reset_fname(code_name)
+        (self.mcoder.start_decoder if decode else self.mcoder.start_encoder)()
+
+    @staticmethod
+    def _host_i32(t, cols=None):
+        t = t.to(torch.int32).cpu()
+        return t.view(-1, cols) if cols else t.view(-1)
+
+    @staticmethod
+    def _host_f32(t):
+        return t.to(torch.float32).cpu().contiguous().view(-1)
+
+    def _plane_tables(self, params, table_op, ncols):
+        """current plane of the context model's output -> (host int32 CDF rows, symbol count); advances `self.ext`"""
+        rows, count = self.ext(params)
+        return self._host_i32(table_op(rows, count), ncols), int(count[0].item())
+
+    def _device_plane(self, host_symbols, h, w):
+        return host_symbols.to(self.cuda_name).view(1, 1, h, w).contiguous()
 
 
 class EntEncoderFast(_Driver):                            # lic360_demo.py:95-141
@@ -93,24 +125,21 @@ class EntEncoderFast(_Driver):                            # lic360_demo.py:95-14
         self.net = self.net.to(self.cuda_name)
 
     def start(self, code_name="./tmp/data"):
-        self.apply(restart_entropy_network)
-        self.mcoder.reset_fname(code_name)
-        self.mcoder.start_encoder()
+        self._open(code_name, decode=False)
 
     @torch.no_grad()
     def forward(self, data, mask):
+        """symbols `data` in {0..bin_num-1} where mask = 1 -> bitstream.  The model sees the centred, masked symbols once per
+        stacked net (weight / sigma / mean); every plane then costs one gather of its 3 x 3 mixture parameters, one table build and
+        one pass of the coder over the plane's symbols."""
         self._begin(data)
-        h, w = data.shape[2:]
-        tdata = ((data - self.bias) * mask).contiguous()
-        y = self.net(torch.cat([tdata, tdata, tdata], dim=0).contiguous())
-        for _ in range(h + w + self.ngroup - 2):
-            z, le = self.ext(y)
-            vec = self.gmm(z, le)
-            ln = int(le[0].item())
-            label, _ = self.ext_label(data)
-            tm, _ = self.ext_mask(mask)
-            pred, tlabel, tm = vec.type(torch.int32).to("cpu"), label.type(torch.int32).to("cpu"), tm.type(torch.float32).to("cpu").contiguous()
-            self.mcoder.encodes_mask(pred.view(-1, self.bin_num + 1), self.bin_num, tlabel.view(-1), tm.view(-1), ln)
+        centred = ((data - self.bias) * mask).contiguous()
+        params = self.net(centred.repeat(3, 1, 1, 1))
+        for _plane in range(self._planes(*data.shape[2:])):
+            tables, count = self._plane_tables(params, self.gmm, self.bin_num + 1)
+            symbols = self._host_i32(self.ext_label(data)[0])
+            coded = self._host_f32(self.ext_mask(mask)[0])
+            self.mcoder.encodes_mask(tables, self.bin_num, symbols, coded, count)
         self.mcoder.end_encoder()
 
 
@@ -134,23 +163,17 @@ class ImpEntEncoderFast(_Driver):                         # lic360_demo.py:143-1
         self.net = self.net.to(self.cuda_name)
 
     def start(self, code_name="./tmp/data"):
-        self.apply(restart_entropy_network)
-        self.mcoder.reset_fname(code_name)
-        self.mcoder.start_encoder()
+        self._open(code_name, decode=False)
 
     @torch.no_grad()
     def forward(self, data):
-        data = data.contiguous()
-        self._begin(data)
-        h, w = data.shape[2:]
-        y = self.net(self.scale(data))
-        for _ in range(h + w + self.ngroup - 2):
-            z, le = self.ext(y)
-            vec = self.table(z, le)
-            ln = int(le[0].item())
-            label, _ = self.ext_label(data)
-            pred, tlabel = vec.view(-1, self.nsym + 1).type(torch.int32).to("cpu"), label.view(-1).type(torch.int32).to("cpu")
-            self.mcoder.encodes(pred, self.nsym, tlabel, ln)
+        """importance levels in {0..bin_num} -> bitstream: one group, softmax tables of nsym entries, nothing masked"""
+        levels = data.contiguous()
+        self._begin(levels)
+        logits = self.net(self.scale(levels))
+        for _plane in range(self._planes(*levels.shape[2:])):
+            tables, count = self._plane_tables(logits, self.table, self.nsym + 1)
+            self.mcoder.encodes(tables, self.nsym, self._host_i32(self.ext_label(levels)[0]), count)
         self.mcoder.end_encoder()
 
 
@@ -174,25 +197,22 @@ class EntDecoder(_Driver):                                # lic360_demo.py:191-2
         self.net = self.net.to(self.cuda_name)
 
     def start(self, code_name="./tmp/data"):
-        self.apply(restart_entropy_network)
-        self.mcoder.reset_fname(code_name)
-        self.mcoder.start_decoder()
+        self._open(code_name, decode=True)
 
     @torch.no_grad()
     def forward(self, mask):
+        """bitstream + mask -> symbols.  Plane p of the model can only be evaluated once planes < p are decoded: `ipt` scatters the
+        previous plane's symbols into the (persistent) model input, the decode-order convolutions extend their outputs by plane p,
+        and the coder turns the plane's tables into symbols (3.5 = "not coded" at masked positions)."""
         h, w = mask.shape[2:]
-        pout = torch.zeros((1, 1, h, w), dtype=torch.float32, device=self.cuda_name)
-        self._begin(pout)
-        for _ in range(h + w + self.ngroup - 2):
-            y = self.net(self.ipt(pout))
-            z, le = self.ext(y)
-            vec = self.gmm(z, le)
-            ln = int(le[0].item())
-            mt, _ = self.ext_mask(mask)
-            pred, mt = vec.type(torch.int32).to("cpu").view(-1, self.bin_num + 1), mt.to("cpu").contiguous().view(-1)
-            pout = self.mcoder.decodes_mask(pred, self.bin_num, mt, ln).to(self.cuda_name).view(1, 1, h, w).contiguous()
-        b = self.ipt(pout)
-        return (b[0:1] + self.bias * mask).contiguous()
+        decoded = torch.zeros((1, 1, h, w), dtype=torch.float32, device=self.cuda_name)
+        self._begin(decoded)
+        for _plane in range(self._planes(h, w)):
+            tables, count = self._plane_tables(self.net(self.ipt(decoded)), self.gmm, self.bin_num + 1)
+            coded = self.ext_mask(mask)[0].cpu().contiguous().view(-1)
+            decoded = self._device_plane(self.mcoder.decodes_mask(tables, self.bin_num, coded, count), h, w)
+        centred = self.ipt(decoded)[0:1]                                  # the last plane's symbols go in with one more scatter
+        return (centred + self.bias * mask).contiguous()
 
 
 class ImpEntDecoder(_Driver):                             # lic360_demo.py:241-290
@@ -217,26 +237,19 @@ class ImpEntDecoder(_Driver):                             # lic360_demo.py:241-2
         self.net = self.net.to(self.cuda_name)
 
     def start(self, code_name="./tmp/data"):
-        self.apply(restart_entropy_network)
-        self.mcoder.reset_fname(code_name)
-        self.mcoder.start_decoder()
+        self._open(code_name, decode=True)
 
     @torch.no_grad()
     def forward(self, h=32, w=64):
-        pout = torch.zeros((1, 1, h, w), dtype=torch.float32, device=self.cuda_name)
-        self._begin(pout)
-        for _ in range(h + w + self.ngroup - 2):
-            y = self.net(self.ipt(pout))
-            z, le = self.ext(y)
-            vec = self.table(z, le)
-            ln = int(le[0].item())
-            pred = vec.type(torch.int32).to("cpu").view(-1, self.nsym + 1)
-            pout = self.mcoder.decodes(pred, self.nsym, ln).to(self.cuda_name).view(1, 1, h, w).contiguous()
-        b = self.ipt(pout)
-        code = ((b + 1) / self.scale).contiguous()
-        tcode = torch.floor(code + 1e-5).type(torch.float32).contiguous()
-        self.last_levels = tcode
-        return self.d2w(self.i2m(tcode))
+        """bitstream -> importance levels [1,1,h,w] (kept in `last_levels`) -> the latent's 0/1 mask [1, 4*bin_num/4, 2h, 2w]"""
+        decoded = torch.zeros((1, 1, h, w), dtype=torch.float32, device=self.cuda_name)
+        self._begin(decoded)
+        for _plane in range(self._planes(h, w)):
+            tables, count = self._plane_tables(self.net(self.ipt(decoded)), self.table, self.nsym + 1)
+            decoded = self._device_plane(self.mcoder.decodes(tables, self.nsym, count), h, w)
+        model_input = self.ipt(decoded)                                   # = level * scale - 1
+        self.last_levels = torch.floor((model_input + 1) / self.scale + 1e-5).to(torch.float32).contiguous()
+        return self.d2w(self.i2m(self.last_levels))
 
 
 def _key_map(prefix):

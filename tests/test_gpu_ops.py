@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle as orc
-from util import conv_params, latent
+from util import conv_params, latent, case_rng
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "g%d_%dto%d_%s" % (c[0], c[1], c[2], "h" if c[3] else "f"))
 def test_cconv_ec_bit_exact(lic, case):
     G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     C, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb, nout, C, act=act)
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
@@ -85,7 +85,7 @@ def test_cconv_ec_matches_masked_conv2d(lic):
                          ids=lambda c: "g%d_%dto%d" % (c[0], c[1], c[2]))
 def test_cconv_dc_planes_bit_exact(lic, case):
     G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     C, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb, nout, C, act=act)
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
@@ -673,7 +673,7 @@ def test_context_layouts(lic):
 def test_cconv4_ec_bit_exact(lic, case):
     import ctypes as C
     G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     Cc, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb, nout, Cc, act=act)
     x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
@@ -729,7 +729,7 @@ def test_cconv4_ec_diag_bit_exact(lic, case):
     """encode-order conv on the wrapped diagonal-major layout (lic360_cconv4_ec_diag) == oracle, incl. the duplicated rows"""
     import ctypes as C
     G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     Cc, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb, nout, Cc, act=act)
     x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
@@ -829,7 +829,7 @@ def test_cconv16_ec_bit_exact(lic, case):
     both cin, cout < 4, group counts that are not multiples of 4, ragged tiles, many samples per XCD, first layers with cin = 4"""
     import ctypes as C
     G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     Cc, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb if nb > 1 else None, nout, Cc, act=act)
     if nb == 1:
@@ -882,7 +882,7 @@ def test_cconv144_ec_bit_exact(lic, case):
     """lic360_cconv144_ec (hidden / last layers of the importance-map net) == oracle; output into the haloed layout or plain NCHW"""
     import ctypes as C
     N, H, W, nout, act, ooff = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     w, b, a, plan, packed = _i144_setup(lic, rng, nout, act)
     x = rng.standard_normal((N, 144, H, W)).astype(np.float32)
     x[rng.random(x.shape) < 0.1] = 0.0
@@ -913,7 +913,7 @@ def test_cconv144_dc_planes_bit_exact(lic, case):
     """decode order on the zero-padded diagonal-major layout: after every plane the persistent output equals the oracle's"""
     import ctypes as C
     N, H, W, nout, act = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    rng = case_rng(case)
     w, b, a, plan, packed = _i144_setup(lic, rng, nout, act)
     x = rng.standard_normal((N, 144, H, W)).astype(np.float32)
     res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
@@ -1068,3 +1068,49 @@ def test_cconv16_dc_planes_bit_exact(lic, case):
             assert np.array_equal(got, want), "plane %d: %d cells differ, max abs diff %g" % (p, int((got != want).sum()), np.abs(got - want).max())
     L.lic360_conv_plan_destroy(plan)
     assert np.array_equal(ref, orc.cconv_ec(x, w, b, a, G, constrain))
+
+
+# ------------------------------------------------------------------ streaming ops at the shapes the bench times
+@pytest.mark.parametrize("shape", [(2, 192, 260, 516), (2, 192, 132, 260), (1, 5, 9, 14), (1, 70000, 6, 7)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_sphere_inplace_and_trim_at_bench_shapes(lic, shape):
+    """in-place apron refresh and trim on the padded planes of the transforms (260x516, 132x260: 16-byte paths, multi-chunk planes), a
+    shape whose padded width is no multiple of 4 (scalar paths) and more than 65535 planes (the fall-back kernels)"""
+    rng = np.random.default_rng(31)
+    y = rng.standard_normal(shape).astype(np.float32)
+    want = orc.sphere_pad_inplace(y.copy(), 2)
+    yd = dev(y)
+    lic.SpherePadOp(2, True, 0, False).forward(yd)
+    assert np.array_equal(host(yd), want)
+    lic.SphereTrimOp(2, 0, False).forward(yd)
+    assert np.array_equal(host(yd), orc.sphere_trim(want.copy(), 2))
+    inner = want[:, :, 2:-2, 2:-2]
+    assert np.array_equal(host(lic.SphereCutEdgeOp(2, 0, False).forward(dev(want))[0]), inner)
+
+
+@pytest.mark.parametrize("shape", [(2, 192, 32, 64), (1, 3, 512, 1024), (1, 66000, 3, 5)], ids=lambda s: "x".join(map(str, s)))
+def test_sphere_pad_at_bench_shapes(lic, shape):
+    """out-of-place pad: latent planes 32x64 -> 36x68, the first layer's 512x1024 image, > 65535 planes"""
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal(shape).astype(np.float32)
+    assert np.array_equal(host(lic.SpherePadOp(2, False, 0, False).forward(dev(x))[0]), orc.sphere_pad(x, 2))
+
+
+def test_pointwise_ops_at_bench_shapes(lic):
+    """dtow / wtod, imp_map, quant, dquant on [2, 192, 32, 64] (what one encode / decode of two 512x1024 images moves)"""
+    rng = np.random.default_rng(33)
+    N, C, H, W, levels = 2, 192, 32, 64, 48
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    up = host(lic.DtowOp(2, True, 0, False).forward(dev(x))[0])
+    assert np.array_equal(up, orc.dtow(x, 2, True)) and up.shape == (N, 48, 64, 128)
+    assert np.array_equal(host(lic.DtowOp(2, False, 0, False).forward(dev(up))[0]), x)
+    imp = np.floor(rng.random((N, 1, H, W)) * levels).astype(np.float32) / levels
+    out = lic.ImpMapOp(levels, 0.1, 1.0, 0.5, 0.61, 0.61, 0, 3, 0, False).forward(dev(x), dev(imp))
+    ro, rm = orc.imp_map(x, imp, levels)
+    assert np.array_equal(host(out[0]), ro) and np.array_equal(host(out[2]), rm)
+    wb = np.concatenate([rng.uniform(-1, 0, (C, 1)), rng.uniform(-2, -0.5, (C, 7))], 1).astype(np.float32)
+    q = lic.QuantOp(C, 8, 0.9, 100, 2, 0.1, 0, False)
+    top, qidx = q.forward(dev(x), dev(wb), dev(np.zeros((C, 8), np.float32)), False)
+    rt, rq, rc = orc.quant(x, wb)
+    assert np.array_equal(host(top), rt) and np.array_equal(host(qidx), rq) and np.array_equal(host(q.count_data_), rc)
+    assert np.array_equal(host(lic.DquantOp(C, 8, 0, False).forward(dev(rq), dev(rm), dev(wb))[0]), orc.dquant(rq, rm, wb))

@@ -2,8 +2,19 @@
 import numpy as np
 
 
+def _stable(key):
+    """a process-independent integer of a (nested) tuple of ints / bools / None / strings: hash() of a tuple holding None depends
+    on the object's address in CPython 3.10, so seeds drawn from it changed from run to run (VERDICT r2 #3b)"""
+    import zlib
+    return zlib.crc32(repr(key).encode())
+
+
 def rng_for(*key):
-    return np.random.default_rng(abs(hash(tuple(key))) % (2 ** 32))
+    return np.random.default_rng(_stable(tuple(key)))
+
+
+def case_rng(case):
+    return np.random.default_rng(_stable(case))
 
 
 def conv_params(rng, nb, nout, C, k=5, act=True):

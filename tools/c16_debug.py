@@ -11,7 +11,7 @@ cases = [(6, 1, 4, False, True, 3, 3, 7, 70), (7, 1, 4, False, False, 1, 1, 33, 
 import itertools
 for case, (use_res, use_zero, rep) in itertools.product(cases, [(0,0,0),(1,0,0),(0,1,0),(1,1,0),(1,1,1)]):
     G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    import zlib; rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
     Cc, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb if nb > 1 else None, nout, Cc, act=act)
     if nb == 1:

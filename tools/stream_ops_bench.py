@@ -24,10 +24,44 @@ def timed(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def selfcheck(device=0):
+    """every timed op once against an independent torch statement of the same map, at the timed shapes (no oracle here: the oracle
+    comparison at these shapes lives in tests/test_gpu_ops.py::test_*_at_bench_shapes) -- a wrong kernel must not be timed"""
+    dev = "cuda:%d" % device
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn((2, 192, 256, 512), device=dev, generator=g)
+    mid = torch.cat([x[..., -2:], x, x[..., :2]], -1)
+    want = torch.cat([mid[:, :, :2].flip(2, 3), mid, mid[:, :, -2:].flip(2, 3)], 2)           # lon wrap, pole rows reflected + mirrored
+    y = want.clone()
+    y[:, :, :2] = 7; y[:, :, -2:] = 7; y[..., :2] = 7; y[..., -2:] = 7
+    lic360.SpherePadOp(2, True, device, False).forward(y)
+    assert torch.equal(y, want), "sphere_pad in place"
+    lic360.SphereTrimOp(2, device, False).forward(y)
+    z = want.clone()
+    z[:, :, :2] = 0; z[:, :, -2:] = 0; z[..., :2] = 0; z[..., -2:] = 0
+    assert torch.equal(y, z), "sphere_trim"
+    v = torch.randn((2, 192, 32, 64), device=dev, generator=g)
+    mid = torch.cat([v[..., -2:], v, v[..., :2]], -1)
+    assert torch.equal(lic360.SpherePadOp(2, False, device, False).forward(v)[0], torch.cat([mid[:, :, :2].flip(2, 3), mid, mid[:, :, -2:].flip(2, 3)], 2)), "sphere_pad"
+    assert torch.equal(lic360.DtowOp(2, True, device, False).forward(v)[0], torch.nn.functional.pixel_shuffle(v, 2)), "dtow"
+    wb = torch.randn((192, 8), device=dev, generator=g).sort(dim=1).values.contiguous()
+    centres = torch.cat([wb[:, :1], wb[:, :1] + torch.cumsum(torch.exp(wb[:, 1:]), 1)], 1)                # quant_cuda.cu:35-43
+    top, qi = lic360.QuantOp(192, 8, 0.9, 100, 2, 0.1, device, False).forward(v, wb, torch.zeros((192, 8), device=dev), False)
+    picked = torch.gather(centres[None, :, None, None, :].expand(2, 192, 32, 64, 8), 4, qi.long()[..., None])[..., 0]
+    d = (v[..., None] - centres[None, :, None, None, :]).abs()
+    assert torch.allclose(top, picked, rtol=1e-4, atol=1e-5), "quant: value = centre of the returned index"
+    assert float(((v - top).abs() > d.min(-1).values * (1 + 1e-4) + 1e-5).float().mean()) < 1e-3, "quant picks the nearest centre"
+    msk = (torch.rand(v.shape, device=dev, generator=g) > 0.3).float()
+    dq = lic360.DquantOp(192, 8, device, False).forward(qi, msk, wb)[0]
+    assert torch.allclose(dq, torch.where(msk > 0.5, picked, centres[None, :, None, None, 0].expand_as(picked)), rtol=1e-4, atol=1e-5), "dquant"
+    return True
+
+
 def measure(batches=(1, 32), device=0):
     """-> rows of {op, images, algorithmic_MB, us, GBps, frac_of_hbm_peak}; called by bench.py (batch 32) and by __main__"""
     dev = "cuda:%d" % device
     rows = []
+    selfcheck(device)
 
     def add(name, n, nbytes, fn):
         t = timed(fn)
