@@ -197,7 +197,7 @@ LIC360_API int lic360_xd_stamps(unsigned long long *host_out, int clear) {
 #endif
 
 template <int CLS>
-__device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *comb, const int lane, const int half) {
+__device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *comb, const int lane, const int whalf) {
     const int G = a.G, H = a.H, W = a.W, S = H + W - 1, C = G * 4, nout = G * a.cout, HP = a.HP;
     const long SKP = a.SKP;
     const int SKP4 = (int)(4 * SKP);
@@ -223,7 +223,11 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
     unsigned span_mask = 0;                                                 // bit j: block gb_hi - j takes one sample per task
     for (int j = 0; j < a.n_gbv; ++j) span_mask |= (window_of(a.gb_hi - j) < 0 ? 1u : 0u) << j;
     span_mask = __builtin_amdgcn_readfirstlane(span_mask);
+#ifdef XD_EXP_HALFWG                                                          // experiment (timing only): 4-wave workgroups, one row half per task, no halo
+    auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? 2 * ns_x : ns_x; };
+#else
     auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? ns_x : (ns_x + 1) >> 1; };
+#endif
     int n_my = 0;
     for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
@@ -234,7 +238,7 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
     // ---- task descriptors.  The walk is software-pipelined: task k + 1 is decoded and its first operand loads are issued BEFORE
     // the epilogue of task k (the operand slots are free then), so no task starts by waiting for memory.
     struct Task {
-        int tc0, s0, n_w, net, pbase, X, nKmax;
+        int tc0, s0, n_w, net, pbase, X, nKmax, half;
         bool span, valid_w;
         const char *xs, *ws;
     };
@@ -247,9 +251,17 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
         t.span = (span_mask >> scan_j) & 1u;
         t.tc0 = gb * XD_GB; t.s0 = a.psum - t.tc0;
         const int T0 = t.span ? 0 : window_of(gb);
+#ifdef XD_EXP_HALFWG
+        const int half = t.span ? (rem & 1) : 0;
+        int n_w = t.span ? xcd + 8 * (rem >> 1) : xcd + 8 * rem;
+        t.valid_w = n_w < a.N;
+#else
+        const int half = whalf;
         int n_w = t.span ? xcd + 8 * rem : xcd + 16 * rem + 8 * half;
         t.valid_w = n_w < a.N;
         if (!t.valid_w) n_w = xcd + 16 * rem;                               // the idle half of an odd pair recomputes sample A and stores nothing
+#endif
+        t.half = half;
         t.n_w = n_w;
         int net = 0;                                                        // n_w / npb without a division (few stacked nets)
         for (int q = a.npb; q <= n_w; q += a.npb) ++net;
@@ -351,7 +363,13 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
     fill(cur);
     for (int kt = 0;; ++kt) {
         const int tc0 = cur.tc0, s0 = cur.s0, n_w = cur.n_w, net = cur.net, pbase = cur.pbase;
+#ifdef XD_EXP_HALFWG
+        const bool span = false, valid_w = cur.valid_w;
+        const int half = 0;
+#else
         const bool span = cur.span, valid_w = cur.valid_w;
+        const int half = cur.half;
+#endif
 #pragma unroll
         for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
         XD_T(0);
@@ -510,11 +528,15 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
 #ifdef XD_STAMP
     if (lane == 0) {
         st[7] += __builtin_amdgcn_s_memtime() - t0;
-        for (int i = 0; i < 8; ++i) xd_stamps[(blockIdx.x * 8 + half * 4 + CLS) * 8 + i] += st[i];
+        for (int i = 0; i < 8; ++i) xd_stamps[((blockIdx.x & 255) * 8 + whalf * 4 + CLS) * 8 + i] += st[i];
     }
 #endif
 }
 
+#ifdef XD_EXP_HALFWG
+#undef XD_THREADS
+#define XD_THREADS 256
+#endif
 __global__ __launch_bounds__(XD_THREADS, 2) void k_cconv16dc(XdArgs a) {
     __shared__ float halo[(2 * 4 + 1) * XD_NHALO * 4];                      // [direction][class][register][channel] + a block of zeros
     for (int i = threadIdx.x; i < XD_NHALO * 4; i += XD_THREADS) halo[2 * 4 * XD_NHALO * 4 + i] = 0.f;
@@ -566,7 +588,11 @@ LIC360_API int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *p, 
     if (gb_hi < 0) return 0;
     a.gb_hi = gb_hi; a.n_gbv = gb_hi - gb_lo + 1;
     ARG_CHECK(a.n_gbv <= 32);
+#ifdef XD_EXP_HALFWG
+    hipLaunchKernelGGL(k_cconv16dc, dim3(512), dim3(XD_THREADS), 0, (hipStream_t)stream, a);
+#else
     hipLaunchKernelGGL(k_cconv16dc, dim3(256), dim3(XD_THREADS), 0, (hipStream_t)stream, a);
+#endif
     LAUNCH_CHECK();
     return 0;
 }
