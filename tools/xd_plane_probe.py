@@ -22,7 +22,9 @@ packed = torch.empty(3 * L.lic360_conv16dc_packed_floats(plan), dtype=torch.floa
 s = lic._stream(0); P = lic._p
 assert L.lic360_conv16dc_pack(s, plan, P(wd), 3, P(packed)) == 0
 nfl = L.lic360_conv4_buffer_floats(0, N * G * 4, H, W)
-x = torch.randn(nfl, dtype=torch.float32, device="cuda:0"); out = torch.zeros(nfl, dtype=torch.float32, device="cuda:0")
+NX = int(os.environ.get("XCOLD", 1))                    # > 1: rotate over this many input buffers, so that every launch reads cold activations
+xs = [torch.randn(nfl, dtype=torch.float32, device="cuda:0") for _ in range(NX)]
+x = xs[0]; out = torch.zeros(nfl, dtype=torch.float32, device="cuda:0")
 packed4 = torch.empty(3 * L.lic360_conv4_packed_floats(plan), dtype=torch.float32, device="cuda:0")
 assert L.lic360_conv4_pack(s, plan, P(wd), 3, P(packed4)) == 0
 has_stamps = hasattr(L, "lic360_xd_stamps")
@@ -31,11 +33,11 @@ try:
 except AttributeError:
     has_stamps = False
 def run(fn, pk, p, reps=20):
-    for _ in range(3): assert fn(s, plan, P(x), P(pk), P(bd), P(ad), None, P(out), N, H, W, 3, p, N) == 0, L.lic360_last_error()
+    for i in range(3): assert fn(s, plan, P(xs[i % NX]), P(pk), P(bd), P(ad), None, P(out), N, H, W, 3, p, N) == 0, L.lic360_last_error()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): fn(s, plan, P(x), P(pk), P(bd), P(ad), None, P(out), N, H, W, 3, p, N)
+    for i in range(reps): fn(s, plan, P(xs[i % NX]), P(pk), P(bd), P(ad), None, P(out), N, H, W, 3, p, N)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 tot16 = tot4 = 0.0
