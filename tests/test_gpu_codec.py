@@ -151,6 +151,24 @@ def test_fused_codec_decode_task_granularity(monkeypatch, gstep, G, H, W, B, see
     assert np.array_equal(fc.decode(ref, dev(mask)).cpu().numpy(), code * mask)
 
 
+@pytest.mark.parametrize("G,H,W,B,seed", [(48, 8, 16, 3, 51), (8, 10, 12, 16, 52), (12, 64, 6, 4, 53)])
+def test_fused_codec_decode_16x16x4_kernel(monkeypatch, G, H, W, B, seed):
+    """LIC360_DC=16: the hidden and last layers of the decode sweep on the input-stationary 16x16x4 MFMA kernel
+    (csrc/cconv16dc_kernels.hip; batches large enough to leave latency mode, 4 | G): decodes the oracle's bitstreams exactly"""
+    from lic360_fused import FusedCodec
+    assert 3 * B * ((G + 2) // 3) > 128 and G % 4 == 0
+    rng = np.random.default_rng(seed)
+    layers = rc.make_main_params(2000 + seed, G)
+    items = [latent(rng, G, H, W) for _ in range(B)]
+    code = np.concatenate([it[0] for it in items], 0)
+    mask = np.concatenate([it[1] for it in items], 0)
+    ref = [rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G) for i in range(B)]
+    monkeypatch.setenv("LIC360_DC", "16")
+    fc = FusedCodec(G, H, W, max_batch=B)
+    fc.load_layers(layers)
+    assert np.array_equal(fc.decode(ref, dev(mask)).cpu().numpy(), code * mask)
+
+
 @pytest.mark.parametrize("cpg,nsym,H,W,B,seed", [(8, 49, 8, 12, 3, 31), (144, 49, 4, 6, 1, 32), (16, 10, 32, 10, 2, 33)])
 def test_fused_importance_codec_matches_oracle(cpg, nsym, H, W, B, seed):
     """Device-resident importance-map stream: byte-identical to the oracle's ImpEntEncoderFast pipeline, exact decode."""

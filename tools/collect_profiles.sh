@@ -1,9 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the rocprofv3 evidence behind profiles/rNN_* -- kernel stats of the default bench,
-# kernel stats of the encode / decode probes alone on the GPU, and the FETCH_SIZE / WRITE_SIZE passes (each counter in its own run).
-# usage: tools/collect_profiles.sh r02      -> gpurun_out/prof_r02/...
+# kernel stats of the encode / decode probes alone on the GPU (decode: the production 4x4x1 kernel and, with LIC360_DC=16, the
+# 16x16x4 kernel), and the FETCH_SIZE / WRITE_SIZE passes (each counter in its own run).
+# usage: tools/collect_profiles.sh r03      -> gpurun_out/prof_r03/...
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -13,13 +14,24 @@ echo bench done
 export PB=48
 rocprofv3 --kernel-trace --stats -d $O/dc -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_probe.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/ec -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_probe.txt 2>&1
+export LIC360_DC=16
+rocprofv3 --kernel-trace --stats -d $O/dc16 -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc16_probe.txt 2>&1
+unset LIC360_DC
 echo probes done
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $O/dc_$C -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_$C.txt 2>&1
   rocprofv3 --kernel-trace --pmc $C -d $O/ec_$C -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_$C.txt 2>&1
+  export LIC360_DC=16
+  rocprofv3 --kernel-trace --pmc $C -d $O/dc16_$C -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc16_$C.txt 2>&1
+  unset LIC360_DC
 done
 echo pmc done
 cd $R
 python3 tools/pmc_traffic.py $O/pmc_traffic.json 48 $O/dc_FETCH_SIZE/p_counter_collection.csv $O/dc_WRITE_SIZE/p_counter_collection.csv \
-    $O/ec_FETCH_SIZE/p_counter_collection.csv $O/ec_WRITE_SIZE/p_counter_collection.csv
+    $O/ec_FETCH_SIZE/p_counter_collection.csv $O/ec_WRITE_SIZE/p_counter_collection.csv \
+    $O/dc16_FETCH_SIZE/p_counter_collection.csv $O/dc16_WRITE_SIZE/p_counter_collection.csv
 python3 tools/stream_ops_bench.py > $O/stream_ops.json
+# keep only the summaries (the traces are hundreds of MB)
+for d in bench dc ec dc16; do cp $O/$d/p_kernel_stats.csv $O/${d}_kernel_stats.csv; done
+rm -rf $O/bench $O/dc $O/ec $O/dc16 $O/*_FETCH_SIZE $O/*_WRITE_SIZE
+ls -la $O

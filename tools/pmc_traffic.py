@@ -3,13 +3,13 @@ PB images, single stream) one --pmc FETCH_SIZE pass and one --pmc WRITE_SIZE pas
 both counters are in KB and count the L2's memory-side requests, Infinity-Cache hits included; on gfx950 FETCH_SIZE reports half of
 the bytes of 16-B-per-lane streaming reads, so it is doubled).  Keys are bench.py's kernel classes.
 
-usage: pmc_traffic.py out.json images  dc_fetch.csv dc_write.csv  ec_fetch.csv ec_write.csv"""
+usage: pmc_traffic.py out.json images  dc_fetch.csv dc_write.csv  ec_fetch.csv ec_write.csv [dc16_fetch.csv dc16_write.csv]"""
 import collections
 import csv
 import json
 import sys
 
-CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16<4, false>", "ec_hidden"),
+CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16dc", "dc_hidden_16x16x4"), ("k_cconv16<4, false>", "ec_hidden"),
            ("k_cconv16<4, true>", "ec_last"), ("k_cconv16<1, false>", "ec_first")]
 out_json, images = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
