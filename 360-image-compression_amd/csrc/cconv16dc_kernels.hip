@@ -542,6 +542,10 @@ __global__ __launch_bounds__(XD_THREADS, 2) void k_cconv16dc(XdArgs a) {
     for (int i = threadIdx.x; i < XD_NHALO * 4; i += XD_THREADS) halo[2 * 4 * XD_NHALO * 4 + i] = 0.f;
     __syncthreads();
     __shared__ float comb[XD_GB * 2 * 4 * 2 * 64];
+#ifdef XD_EXP_LONE                                                            // experiment: one workgroup per CU (LDS ballast)
+    __shared__ float ballast[24 * 1024];
+    if (a.N < 0) { ballast[threadIdx.x] = 1.f; __syncthreads(); comb[threadIdx.x] = ballast[threadIdx.x ^ 1]; }
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cls = wave & 3, half = wave >> 2;
 #ifdef XD_EXP_EMPTY
