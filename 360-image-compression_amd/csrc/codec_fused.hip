@@ -374,6 +374,110 @@ __device__ __forceinline__ int ac_decode_symbol8(AcState &s, R &bits, uint32_t w
     s.low = low; s.high = high; s.code = code;
     return sym;
 }
+// The same symbol step in ~90 scalar instructions instead of ~125 (the serial chain is a lone wave issuing one instruction every
+// 4-5 cycles, so its length IS the decode latency of an image: 58 of 117 ms before).  Differences, all exact:
+//   * interval start  floor(T * range >> 16)  as ONE s_mul_hi_u32 of (T << 16) and range (range < 2^32; range == 2^32, possible
+//     only while low = 0 and high = 2^32 - 1, takes the general function above);
+//   * the underflow run of the code register as one shift and one XOR: while low = 01.., high = 10.. and low <= code <= high, the
+//     second bit of code is the complement of its first, so  (code & TOP) | ((code << 1) & ~TOP)  ==  (code << 1) ^ TOP, and n2
+//     such steps are (code << n2) ^ TOP; with the n1 plain shifts before them: code' = ((code << n) | next n bits) ^ (n2 ? TOP : 0);
+//   * high is carried complemented through both shift runs ( ~((~h) << n) == (h << n) | ones(n) ).
+// The interval part (three probes, new low / high, both renormalisation runs) is ONE scalar inline-asm block of 55 instructions:
+// from C++ hipcc spends ~100 on it (every comparison is materialised as a 64-bit lane mask and turned back into SCC, the symbol is
+// assembled on the VALU, range == 2^32 is detected with a vector add).
+__device__ __forceinline__ int ac_decode_symbol8_fast(AcState &s, DevBits &rd, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ww) {
+    uint32_t low = s.low, high = s.high;
+    int sym, n1, n2;
+    uint32_t r1, off, rng, full, bb, bm, tt, lo, hi, t0, w3, t1;
+    asm("s_sub_u32 %5, %1, %0\n\t"                 // r1 = high - low
+        "s_sub_u32 %6, %17, %0\n\t"                // offset = code - low
+        "s_add_u32 %7, %5, 1\n\t"                  // range (mod 2^32); SCC = (range == 2^32)
+        "s_cselect_b32 %8, -1, 0\n\t"              // full: start(T) = T << 16 then (the multiply yields 0)
+        "s_lshl_b32 %11, %18, 16\n\t"              // ---- probe 1: T[4]
+        "s_mul_hi_u32 %9, %11, %7\n\t"
+        "s_and_b32 %14, %11, %8\n\t"
+        "s_or_b32 %9, %9, %14\n\t"                 // b = floor(T * range >> 16)
+        "s_add_u32 %10, %9, -1\n\t"                // b - 1
+        "s_and_b32 %14, %19, 0xffff0000\n\t"       // T[6] << 16
+        "s_lshl_b32 %16, %19, 16\n\t"              // T[2] << 16
+        "s_cmp_ge_u32 %6, %9\n\t"                  // c1
+        "s_cselect_b32 %12, %9, 0\n\t"             // lo
+        "s_cselect_b32 %13, %5, %10\n\t"           // him1
+        "s_cselect_b32 %2, 4, 0\n\t"               // sym
+        "s_cselect_b32 %11, %14, %16\n\t"
+        "s_cselect_b32 %15, %21, %20\n\t"          // next word: T[5]|T[7] : T[1]|T[3]
+        "s_mul_hi_u32 %9, %11, %7\n\t"             // ---- probe 2: T[6] : T[2]
+        "s_and_b32 %14, %11, %8\n\t"
+        "s_or_b32 %9, %9, %14\n\t"
+        "s_add_u32 %10, %9, -1\n\t"
+        "s_and_b32 %14, %15, 0xffff0000\n\t"
+        "s_lshl_b32 %16, %15, 16\n\t"
+        "s_cmp_ge_u32 %6, %9\n\t"                  // c2
+        "s_cselect_b32 %12, %9, %12\n\t"
+        "s_cselect_b32 %13, %13, %10\n\t"
+        "s_cselect_b32 %11, %14, %16\n\t"
+        "s_cselect_b32 %14, 2, 0\n\t"
+        "s_or_b32 %2, %2, %14\n\t"
+        "s_mul_hi_u32 %9, %11, %7\n\t"             // ---- probe 3: T[7] : T[5] : T[3] : T[1]
+        "s_and_b32 %14, %11, %8\n\t"
+        "s_or_b32 %9, %9, %14\n\t"
+        "s_add_u32 %10, %9, -1\n\t"
+        "s_cmp_ge_u32 %6, %9\n\t"                  // c3
+        "s_cselect_b32 %12, %9, %12\n\t"
+        "s_cselect_b32 %13, %13, %10\n\t"
+        "s_cselect_b32 %14, 1, 0\n\t"
+        "s_or_b32 %2, %2, %14\n\t"
+        "s_add_u32 %13, %0, %13\n\t"               // ---- high' = low + him1, low' = low + lo
+        "s_add_u32 %0, %0, %12\n\t"
+        "s_not_b32 %14, %13\n\t"                   // high travels complemented: ~((~h) << n) == (h << n) | ones(n)
+        "s_xor_b32 %9, %0, %13\n\t"
+        "s_or_b32 %9, %9, 1\n\t"                   // (low == high: n1 = 31, flagged by ac_state_check at the end of the launch)
+        "s_flbit_i32_b32 %3, %9\n\t"               // n1: leading bits on which low and high agree
+        "s_lshl_b32 %0, %0, %3\n\t"
+        "s_lshl_b32 %14, %14, %3\n\t"
+        "s_and_b32 %9, %0, %14\n\t"                // low = 01.., high = 10..
+        "s_lshl_b32 %9, %9, 1\n\t"
+        "s_not_b32 %9, %9\n\t"
+        "s_flbit_i32_b32 %4, %9\n\t"               // n2: underflow run
+        "s_min_u32 %4, %4, 30\n\t"
+        "s_lshl_b32 %0, %0, %4\n\t"
+        "s_bitset0_b32 %0, 31\n\t"
+        "s_lshl_b32 %14, %14, %4\n\t"
+        "s_orn2_b32 %1, 0x80000000, %14"
+        : "+s"(low), "+s"(high), "=&s"(sym), "=&s"(n1), "=&s"(n2), "=&s"(r1), "=&s"(off), "=&s"(rng), "=&s"(full), "=&s"(bb), "=&s"(bm),
+          "=&s"(tt), "=&s"(lo), "=&s"(hi), "=&s"(t0), "=&s"(w3), "=&s"(t1)
+        : "s"(s.code), "s"(wx), "s"(wy), "s"(wz), "s"(ww)
+        : "scc");
+    s.low = low; s.high = high;
+    // n = n1 + n2 <= 18: a selected symbol has T[sym+1] - T[sym] >= 1 of 65536 (a zero-width entry is never selected: offset >= b and
+    // offset < b cannot both hold) and range > 2^30 before the step, so the new range is >= 2^14: low' and high' agree on at most 18
+    // leading bits, and every underflow bit halves what is left of that budget.  One 32-bit refill therefore always covers the read,
+    // whatever the stream holds.  The refill is branch-free: a conditional update of the reader state costs a dozen register copies.
+    if (__builtin_expect(rd.pos >= rd.wbase + 256, 0)) rd.fetch_window();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rd.win, (rd.pos - rd.wbase) >> 2);
+    unsigned long long acc = rd.acc, bits, t64;
+    int nacc = rd.nacc, pos = rd.pos, n, u0, u1;
+    asm("s_lshl_b64 %4, %0, 32\n\t"                // acc << 32 | w
+        "s_or_b64 %4, %4, %10\n\t"
+        "s_add_u32 %5, %8, %9\n\t"                 // n
+        "s_cmp_lt_i32 %1, %5\n\t"                  // fewer than n bits in the accumulator: append the next stream word
+        "s_cselect_b64 %0, %4, %0\n\t"
+        "s_cselect_b32 %6, 32, 0\n\t"
+        "s_cselect_b32 %7, 4, 0\n\t"
+        "s_add_u32 %2, %2, %7\n\t"                 // pos
+        "s_add_u32 %1, %1, %6\n\t"
+        "s_sub_u32 %1, %1, %5\n\t"                 // nacc
+        "s_lshr_b64 %3, %0, %1\n\t"                // the next n bits: (acc >> nacc) & ones(n)
+        "s_lshl_b64 %4, -1, %5\n\t"
+        "s_andn2_b64 %3, %3, %4"
+        : "+s"(acc), "+s"(nacc), "+s"(pos), "=&s"(bits), "=&s"(t64), "=&s"(n), "=&s"(u0), "=&s"(u1)
+        : "s"(n1), "s"(n2), "s"((unsigned long long)w)
+        : "scc");
+    // code' = ((code << n) | bits) ^ (n2 ? TOP : 0), see above (n1 <= 31 and n2 <= 30: two 32-bit shifts)
+    s.code = (((s.code << n1) << n2) | (uint32_t)bits) ^ ((uint32_t)(n2 != 0) << 31);
+    rd.acc = acc; rd.nacc = nacc; rd.pos = pos;
+    return sym;
+}
 __device__ __forceinline__ void ac_state_check(AcState &s) {
     const uint32_t r1 = s.high - s.low;
     if (s.low >= s.high || r1 < (1u << 30) + 1u) s.error = 2;
@@ -456,8 +560,9 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
             todo &= todo - 1;
             const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)tcur.x, j), wy = (uint32_t)__builtin_amdgcn_readlane((int)tcur.y, j);
             const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)tcur.z, j), ww = (uint32_t)__builtin_amdgcn_readlane((int)tcur.w, j);
-            const int sym = ac_decode_symbol8(st, rd, wx, wy, wz, ww);
-            symv = (lane == j) ? sym : symv;
+            const int sym = ac_decode_symbol8_fast(st, rd, wx, wy, wz, ww);
+            // (lane j of symv <- sym; clang exposes no writelane builtin.  The s_nop covers the SALU-writes-m0 -> lane-select hazard)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(symv) : "s"(sym), "s"(j) : "m0");   // (two SGPR sources: the lane select goes through m0)
         }
         if (live) {
             if constexpr (LINEAR) code_out[(long)b * G + start + base + lane] = coded ? (float)symv : 0.0f;
