@@ -206,17 +206,65 @@ __global__ __launch_bounds__(128) void k_ac_encode(const uint2 *__restrict__ rec
                 const uint2 v2 = load_rec(64 * g + 128);
                 unsigned long long todo = __ballot(v.y != 0u);            // hi == 0: not coded (mask < 0.5, coder.cpp:79)
                 uint2 o = make_uint2(0u, 0u);
+                uint32_t low = st.low, high = st.high, serr = st.error;
                 while (todo) {
                     const int j = __builtin_ctzll(todo);
                     todo &= todo - 1;
                     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v.x, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)v.y, j);
-                    int n1, n2;
-                    uint32_t lowb;
-                    ac_narrow(st, lo, hi, 65536u, n1, n2, lowb);
-                    const uint32_t meta = (uint32_t)n1 | ((uint32_t)n2 << 8) | 0x10000u;
-                    o.x = lane == j ? lowb : o.x;
-                    o.y = lane == j ? meta : o.y;
+                    // ac_narrow (ac_core.h) for total = 2^16 as 41 scalar instructions (hipcc: 60+): interval starts as one s_mul_hi_u32 of
+                    // (T << 16) and range (range == 2^32: T << 16 itself; T = 65536 = the end of the table: the whole range), high carried
+                    // complemented through the two shift runs, the faults as sticky bits (1: empty symbol, 2: range too small).
+                    uint32_t lowb, meta, r1, rng, full, sa, sb, t0, tt;
+                    asm("s_sub_u32 %5, %1, %0\n\t"                 // r1 = high - low
+                        "s_cmp_lt_u32 %5, 0x40000001\n\t"          // range < 2^30 + 2 (ArithmeticCoder.cpp:44-45)
+                        "s_cselect_b32 %10, 2, 0\n\t"
+                        "s_or_b32 %2, %2, %10\n\t"
+                        "s_add_u32 %6, %5, 1\n\t"                  // range (mod 2^32); SCC = (range == 2^32)
+                        "s_cselect_b32 %7, -1, 0\n\t"
+                        "s_lshl_b32 %11, %12, 16\n\t"
+                        "s_mul_hi_u32 %8, %11, %6\n\t"
+                        "s_and_b32 %10, %11, %7\n\t"
+                        "s_or_b32 %8, %8, %10\n\t"                 // floor(symLow * range >> 16)
+                        "s_lshl_b32 %11, %13, 16\n\t"
+                        "s_mul_hi_u32 %9, %11, %6\n\t"
+                        "s_and_b32 %10, %11, %7\n\t"
+                        "s_or_b32 %9, %9, %10\n\t"
+                        "s_add_u32 %9, %9, -1\n\t"                 // floor(symHigh * range >> 16) - 1
+                        "s_cmp_eq_u32 %11, 0\n\t"                  // symHigh = 65536
+                        "s_cselect_b32 %9, %5, %9\n\t"
+                        "s_cmp_ge_u32 %12, %13\n\t"                // symLow >= symHigh (ArithmeticCoder.cpp:41-42)
+                        "s_cselect_b32 %10, 1, 0\n\t"
+                        "s_or_b32 %2, %2, %10\n\t"
+                        "s_add_u32 %9, %0, %9\n\t"                 // high'
+                        "s_add_u32 %0, %0, %8\n\t"                 // low'
+                        "s_mov_b32 %3, %0\n\t"                     // the low word before the shift: its top bits are the output
+                        "s_not_b32 %10, %9\n\t"
+                        "s_xor_b32 %8, %0, %9\n\t"
+                        "s_or_b32 %8, %8, 1\n\t"
+                        "s_flbit_i32_b32 %4, %8\n\t"               // n1
+                        "s_lshl_b32 %0, %0, %4\n\t"
+                        "s_lshl_b32 %10, %10, %4\n\t"
+                        "s_and_b32 %8, %0, %10\n\t"
+                        "s_lshl_b32 %8, %8, 1\n\t"
+                        "s_not_b32 %8, %8\n\t"
+                        "s_flbit_i32_b32 %8, %8\n\t"               // n2
+                        "s_min_u32 %8, %8, 30\n\t"
+                        "s_lshl_b32 %0, %0, %8\n\t"
+                        "s_bitset0_b32 %0, 31\n\t"
+                        "s_lshl_b32 %10, %10, %8\n\t"
+                        "s_orn2_b32 %1, 0x80000000, %10\n\t"
+                        "s_lshl_b32 %8, %8, 8\n\t"
+                        "s_or_b32 %4, %4, %8\n\t"
+                        "s_bitset1_b32 %4, 16"                     // meta = n1 | n2 << 8 | coded << 16
+                        : "+s"(low), "+s"(high), "+s"(serr), "=&s"(lowb), "=&s"(meta), "=&s"(r1), "=&s"(rng), "=&s"(full), "=&s"(sa), "=&s"(sb),
+                          "=&s"(t0), "=&s"(tt)
+                        : "s"(lo), "s"(hi)
+                        : "scc");
+                    // lane j of o <- (lowb, meta)  (two SGPR sources per v_writelane: the lane select goes through m0; the s_nop covers m0's hazard)
+                    asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                                 : "+v"(o.x), "+v"(o.y) : "s"(lowb), "s"(meta), "s"(j) : "m0");
                 }
+                st.low = low; st.high = high; st.error = serr;
                 ring[g & 1][lane] = o;
                 v = v1; v1 = v2;
             }

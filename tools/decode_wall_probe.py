@@ -1,4 +1,4 @@
-"""single-stream decode wall time of PB images of the latent stream with per-launch events off (dc_probe.py turns them on)"""
+"""single-stream encode / decode wall time of PB images of the latent stream with per-launch events off (dc_probe.py turns them on)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("360-image-compression_amd", "tests"):
@@ -12,9 +12,18 @@ items = [latent(np.random.default_rng(i), G, H, W) for i in range(B)]
 code = torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask = torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
 st = torch.cuda.Stream()
 fc.encode_async(code, mask); torch.cuda.synchronize()
+for rep in range(3):
+    t0 = time.time()
+    with torch.cuda.stream(st):
+        fc.encode_async(code, mask)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print("B %d encode %d: %.1f ms" % (B, rep, dt * 1e3), flush=True)
 for rep in range(4):
     t0 = time.time()
     with torch.cuda.stream(st):
         fc.decode_async(mask, B)
     torch.cuda.synchronize(); dt = time.time() - t0
     print("B %d decode %d: %.1f ms, exact %s" % (B, rep, dt * 1e3, bool(torch.equal(fc.code_out[:B], code * mask))), flush=True)
+fc.profile(True)
+fc.encode_async(code, mask); fc.decode_async(mask, B); torch.cuda.synchronize()
+print("per kernel class (ms, launches):", {k: (round(v[0], 2), v[1]) for k, v in fc.profile_read().items() if v[1]})
