@@ -49,7 +49,7 @@ struct lic360_codec {
     uint2 *e_rec;
     float *d_x0, *d_act[11], *d_y;
     AcDevState *d_state;
-    uint4 *d_tab = nullptr;                    // per-plane CDF tables [maxB][tab_pitch] (k_dec_tables -> k_dec_plane)
+    uint4 *d_tab = nullptr;                    // per-plane CDF tables [maxB][tab_pitch][2] (k_dec_tables -> k_dec_plane)
     int tab_pitch = 0;
     bool layer_set[12];
     // optional per-kernel-class timing (bench.py's instrumented pass; off in the timed region): HIP event pairs around
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(128) void k_ac_encode(const uint2 *__restrict__ rec
                         : "scc");
                     // lane j of o <- (lowb, meta)  (two SGPR sources per v_writelane: the lane select goes through m0; the s_nop covers m0's hazard)
                     asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                                 : "+v"(o.x), "+v"(o.y) : "s"(lowb), "s"(meta), "s"(j) : "m0");
+                                 : "+v"(o.x), "+v"(o.y) : "s"(lowb), "s"(meta), "s"(j));   // (m0 is not in the clobber list: hipcc treats it as reserved and uses it for nothing in this kernel -- gfx9 LDS instructions do not read it)
                 }
                 st.low = low; st.high = high; st.error = serr;
                 ring[g & 1][lane] = o;
@@ -364,143 +364,85 @@ struct DevBits {
     }
 };
 
-// 8-symbol tables travel as ONE uint4 per symbol: the 7 inner CDF entries (each <= 65535 because T[8] = 65536 and the entries
-// increase) as 16-bit halves in binary-search order, plus the "coded" flag:
-//   x = T[4] | coded << 16,  y = T[2] | T[6] << 16,  z = T[1] | T[3] << 16,  w = T[5] | T[7] << 16
-__device__ __forceinline__ uint4 dec_pack8(const int *T) {
-    return make_uint4((unsigned)T[4] | 0x10000u, (unsigned)T[2] | ((unsigned)T[6] << 16), (unsigned)T[1] | ((unsigned)T[3] << 16),
-                      (unsigned)T[5] | ((unsigned)T[7] << 16));
+// 8-symbol tables travel as EIGHT words per symbol, word k = T[k] << 16 (T[0] = 0; T[8] = 65536 is implicit; an uncoded symbol is
+// all zeros, a coded one has T[7] >= 7): the decoder loads 8 symbols per VGPR -- lane 8q + k holds word k of the q-th -- so that ONE
+// v_mul_hi_u32 yields all eight interval starts of a symbol and one v_cmp finds it (ac_decode_symbol8_v).  The inner entries are
+// <= 65535 because T[8] = 65536 and the entries increase.
+__device__ __forceinline__ void dec_pack8(const int *T, uint4 &a, uint4 &b) {
+    a = make_uint4(0u, (unsigned)T[1] << 16, (unsigned)T[2] << 16, (unsigned)T[3] << 16);
+    b = make_uint4((unsigned)T[4] << 16, (unsigned)T[5] << 16, (unsigned)T[6] << 16, (unsigned)T[7] << 16);
 }
 // One symbol of the serial decode chain, wave-uniform, without a division.  ArithmeticDecoder::read (ArithmeticCoder.cpp:82-116)
 // finds value = ((offset+1)*total - 1) / range and the symbol with T[sym] <= value < T[sym+1]; since
 //   value >= T[k]  <=>  (offset+1)*total > T[k]*range  <=>  offset >= floor(T[k]*range / total)
-// the symbol is the number of k in 1..7 whose interval start  floor(T[k]*range >> 16)  is <= offset -- three binary-search
-// probes, each one multiply -- and the probes that bracket it ARE the new low / high of ac_narrow.  range = high-low+1 can be
-// 2^32, so the product is formed as T*(range-1) + T.
-// The reference's range / consistency assertions (errors 2 and 3 of ac_core.h) cannot fire inside this function: the symbol is
-// chosen so that low+lo <= code <= low+him1, and the renormalisation maps that interval and the code by the same shifts.  They
-// are checked once per launch on the state that enters and leaves (ac_state_check) instead of per symbol.
-template <class R>
-__device__ __forceinline__ int ac_decode_symbol8(AcState &s, R &bits, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ww) {
-    const uint32_t r1 = s.high - s.low, offset = s.code - s.low;
-    auto start = [&](uint32_t t) { return (uint32_t)(((uint64_t)t * r1 + t) >> 16); };
-    uint32_t lo = 0, him1 = r1;                                         // interval [lo, him1] relative to low
-    uint32_t b = start(wx & 0xffffu);
-    const bool c1 = offset >= b;
-    int sym = c1 ? 4 : 0;
-    if (c1) lo = b; else him1 = b - 1;
-    b = start(c1 ? wy >> 16 : wy & 0xffffu);
-    const bool c2 = offset >= b;
-    sym |= c2 ? 2 : 0;
-    if (c2) lo = b; else him1 = b - 1;
-    const uint32_t w3 = c1 ? ww : wz;
-    b = start(c2 ? w3 >> 16 : w3 & 0xffffu);
-    const bool c3 = offset >= b;
-    sym |= c3 ? 1 : 0;
-    if (c3) lo = b; else him1 = b - 1;
-    uint32_t low = s.low + lo, high = s.low + him1;
-    // renormalisation: the closed forms of ac_narrow
-    int n1 = ac_clz32(low ^ high);
-    if (n1 > 31) n1 = 31;                                               // low == high: flagged by ac_state_check at the end of the launch
-    const uint32_t code1_msb = (s.code << n1) & 0x80000000u;             // bit 31 after the shift run (survives the underflow run)
-    low <<= n1;
-    high = (high << n1) | ((1u << n1) - 1u);
-    int n2 = ac_clz32(~((low & ~high) << 1));
-    if (n2 > 30) n2 = 30;
-    low = (low << n2) & 0x7fffffffu;
-    high = ((high << n2) & 0x7fffffffu) | 0x80000000u | ((1u << n2) - 1u);
-    const int n = n1 + n2;
-    uint32_t code;
-    if (n <= 32) {                                                      // both runs' bits in one read
-        const uint32_t nb = bits.get(n);
-        code = code1_msb | (((n == 32 ? 0u : s.code << n) | nb) & 0x7fffffffu);
-        if (n2 == 0) code = (s.code << n1) | nb;
-    } else {
-        code = (s.code << n1) | bits.get(n1);
-        code = (code & 0x80000000u) | ((code << n2) & 0x7fffffffu) | bits.get(n2);
-    }
-    s.low = low; s.high = high; s.code = code;
-    return sym;
-}
-// The same symbol step in ~90 scalar instructions instead of ~125 (the serial chain is a lone wave issuing one instruction every
-// 4-5 cycles, so its length IS the decode latency of an image: 58 of 117 ms before).  Differences, all exact:
-//   * interval start  floor(T * range >> 16)  as ONE s_mul_hi_u32 of (T << 16) and range (range < 2^32; range == 2^32, possible
-//     only while low = 0 and high = 2^32 - 1, takes the general function above);
+// the symbol is the number of k in 1..7 whose interval start  floor(T[k]*range >> 16)  is <= offset, and the starts that bracket
+// it ARE the new low / high of ac_narrow.
+// The chain is a lone wave issuing one instruction every 4-5 cycles, so its length in instructions IS the decode latency of an
+// image.  ~72 instructions per coded symbol (round 2: 125 from C++; hipcc materialises every comparison as a lane mask, assembles
+// small integers on the VALU ...), the serial core as inline assembly:
+//   * all eight starts at once: v_mul_hi_u32 of the symbol's eight lanes (T[k] << 16) with range -- floor(T*range >> 16) exactly,
+//     range < 2^32; range == 2^32 (whenever low = 0, high = 2^32 - 1 recurs) selects T << 16 itself -- one v_cmp against offset,
+//     a popcount of the symbol's 8 flag bits, two v_readlane for the bracketing starts (T[8]: him1 = range - 1);
 //   * the underflow run of the code register as one shift and one XOR: while low = 01.., high = 10.. and low <= code <= high, the
 //     second bit of code is the complement of its first, so  (code & TOP) | ((code << 1) & ~TOP)  ==  (code << 1) ^ TOP, and n2
 //     such steps are (code << n2) ^ TOP; with the n1 plain shifts before them: code' = ((code << n) | next n bits) ^ (n2 ? TOP : 0);
-//   * high is carried complemented through both shift runs ( ~((~h) << n) == (h << n) | ones(n) ).
-// The interval part (three probes, new low / high, both renormalisation runs) is ONE scalar inline-asm block of 55 instructions:
-// from C++ hipcc spends ~100 on it (every comparison is materialised as a 64-bit lane mask and turned back into SCC, the symbol is
-// assembled on the VALU, range == 2^32 is detected with a vector add).
-__device__ __forceinline__ int ac_decode_symbol8_fast(AcState &s, DevBits &rd, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ww) {
+//   * high is carried complemented through both shift runs ( ~((~h) << n) == (h << n) | ones(n) );
+//   * n = n1 + n2 <= 18: a selected symbol has T[sym+1] - T[sym] >= 1 of 65536 (a zero-width entry is never selected: offset >= b
+//     and offset < b cannot both hold) and range > 2^30 before the step, so the new range is >= 2^14: low' and high' agree on at most
+//     18 leading bits, and every underflow bit halves what is left of that budget.  One branch-free 32-bit refill therefore covers
+//     every read, whatever the stream holds (a conditional update of the reader state costs a dozen register copies per symbol).
+// The reference's range / consistency assertions (errors 2 and 3 of ac_core.h) cannot fire inside this function: the symbol is
+// chosen so that low+lo <= code <= low+him1, and the renormalisation maps that interval and the code by the same shifts.  They
+// are checked once per launch on the state that enters and leaves (ac_state_check) instead of per symbol.
+// tv: the table words of 8 symbols (dec_pack8), L: first lane of this symbol's eight.
+__device__ __forceinline__ int ac_decode_symbol8_v(AcState &s, DevBits &rd, uint32_t tv, int L) {
     uint32_t low = s.low, high = s.high;
     int sym, n1, n2;
-    uint32_t r1, off, rng, full, bb, bm, tt, lo, hi, t0, w3, t1;
-    asm("s_sub_u32 %5, %1, %0\n\t"                 // r1 = high - low
-        "s_sub_u32 %6, %17, %0\n\t"                // offset = code - low
-        "s_add_u32 %7, %5, 1\n\t"                  // range (mod 2^32); SCC = (range == 2^32)
-        "s_cselect_b32 %8, -1, 0\n\t"              // full: start(T) = T << 16 then (the multiply yields 0)
-        "s_lshl_b32 %11, %18, 16\n\t"              // ---- probe 1: T[4]
-        "s_mul_hi_u32 %9, %11, %7\n\t"
-        "s_and_b32 %14, %11, %8\n\t"
-        "s_or_b32 %9, %9, %14\n\t"                 // b = floor(T * range >> 16)
-        "s_add_u32 %10, %9, -1\n\t"                // b - 1
-        "s_and_b32 %14, %19, 0xffff0000\n\t"       // T[6] << 16
-        "s_lshl_b32 %16, %19, 16\n\t"              // T[2] << 16
-        "s_cmp_ge_u32 %6, %9\n\t"                  // c1
-        "s_cselect_b32 %12, %9, 0\n\t"             // lo
-        "s_cselect_b32 %13, %5, %10\n\t"           // him1
-        "s_cselect_b32 %2, 4, 0\n\t"               // sym
-        "s_cselect_b32 %11, %14, %16\n\t"
-        "s_cselect_b32 %15, %21, %20\n\t"          // next word: T[5]|T[7] : T[1]|T[3]
-        "s_mul_hi_u32 %9, %11, %7\n\t"             // ---- probe 2: T[6] : T[2]
-        "s_and_b32 %14, %11, %8\n\t"
-        "s_or_b32 %9, %9, %14\n\t"
-        "s_add_u32 %10, %9, -1\n\t"
-        "s_and_b32 %14, %15, 0xffff0000\n\t"
-        "s_lshl_b32 %16, %15, 16\n\t"
-        "s_cmp_ge_u32 %6, %9\n\t"                  // c2
-        "s_cselect_b32 %12, %9, %12\n\t"
-        "s_cselect_b32 %13, %13, %10\n\t"
-        "s_cselect_b32 %11, %14, %16\n\t"
-        "s_cselect_b32 %14, 2, 0\n\t"
-        "s_or_b32 %2, %2, %14\n\t"
-        "s_mul_hi_u32 %9, %11, %7\n\t"             // ---- probe 3: T[7] : T[5] : T[3] : T[1]
-        "s_and_b32 %14, %11, %8\n\t"
-        "s_or_b32 %9, %9, %14\n\t"
-        "s_add_u32 %10, %9, -1\n\t"
-        "s_cmp_ge_u32 %6, %9\n\t"                  // c3
-        "s_cselect_b32 %12, %9, %12\n\t"
-        "s_cselect_b32 %13, %13, %10\n\t"
-        "s_cselect_b32 %14, 1, 0\n\t"
-        "s_or_b32 %2, %2, %14\n\t"
-        "s_add_u32 %13, %0, %13\n\t"               // ---- high' = low + him1, low' = low + lo
-        "s_add_u32 %0, %0, %12\n\t"
-        "s_not_b32 %14, %13\n\t"                   // high travels complemented: ~((~h) << n) == (h << n) | ones(n)
-        "s_xor_b32 %9, %0, %13\n\t"
-        "s_or_b32 %9, %9, 1\n\t"                   // (low == high: n1 = 31, flagged by ac_state_check at the end of the launch)
-        "s_flbit_i32_b32 %3, %9\n\t"               // n1: leading bits on which low and high agree
+    uint32_t r1, off, rng, lo, hi, t0, t1, t2, stv;
+    unsigned long long fm, fl;
+    // (three statements: hipcc treats EVERY result of an asm statement as divergent as soon as one of them is a vector register)
+    asm("s_sub_u32 %0, %5, %4\n\t"                 // r1 = high - low
+        "s_sub_u32 %1, %6, %4\n\t"                 // offset = code - low
+        "s_add_u32 %2, %0, 1\n\t"                  // range (mod 2^32); SCC = (range == 2^32)
+        "s_cselect_b64 %3, -1, 0"
+        : "=&s"(r1), "=&s"(off), "=&s"(rng), "=&s"(fm) : "s"(low), "s"(high), "s"(s.code) : "scc");
+    asm("v_mul_hi_u32 %0, %1, %2\n\t"              // the eight interval starts floor(T[k] * range >> 16) of every symbol in tv
+        "v_cndmask_b32_e64 %0, %0, %1, %3"         // range == 2^32: T[k] << 16
+        : "=&v"(stv) : "v"(tv), "s"(rng), "s"(fm));
+    asm("v_cmp_le_u32_e64 vcc, %12, %13\n\t"
+        "s_or_b32 %7, %14, 0x80000\n\t"            // bit field: offset L, width 8
+        "s_bfe_u64 %10, vcc, %7\n\t"
+        "s_bcnt1_i32_b64 %8, %10\n\t"              // 1 + sym (start 0 = 0 always passes; the starts increase)
+        "s_add_u32 %9, %14, %8\n\t"                // lane of start[sym + 1]
+        "s_add_u32 %7, %9, -1\n\t"
+        "v_readlane_b32 %5, %12, %7\n\t"           // lo = start[sym]
+        "v_readlane_b32 %6, %12, %9\n\t"
+        "s_add_u32 %6, %6, -1\n\t"                 // him1 = start[sym + 1] - 1 ...
+        "s_cmp_eq_u32 %8, 8\n\t"
+        "s_cselect_b32 %6, %11, %6\n\t"            // ... or range - 1 for the last symbol
+        "s_add_u32 %2, %8, -1\n\t"
+        "s_add_u32 %6, %0, %6\n\t"                 // ---- high' = low + him1, low' = low + lo
+        "s_add_u32 %0, %0, %5\n\t"
+        "s_not_b32 %7, %6\n\t"                     // high travels complemented
+        "s_xor_b32 %5, %0, %6\n\t"
+        "s_or_b32 %5, %5, 1\n\t"                   // (low == high: n1 = 31, flagged by ac_state_check at the end of the launch)
+        "s_flbit_i32_b32 %3, %5\n\t"               // n1: leading bits on which low and high agree
         "s_lshl_b32 %0, %0, %3\n\t"
-        "s_lshl_b32 %14, %14, %3\n\t"
-        "s_and_b32 %9, %0, %14\n\t"                // low = 01.., high = 10..
-        "s_lshl_b32 %9, %9, 1\n\t"
-        "s_not_b32 %9, %9\n\t"
-        "s_flbit_i32_b32 %4, %9\n\t"               // n2: underflow run
+        "s_lshl_b32 %7, %7, %3\n\t"
+        "s_and_b32 %5, %0, %7\n\t"                 // low = 01.., high = 10..
+        "s_lshl_b32 %5, %5, 1\n\t"
+        "s_not_b32 %5, %5\n\t"
+        "s_flbit_i32_b32 %4, %5\n\t"               // n2: underflow run
         "s_min_u32 %4, %4, 30\n\t"
         "s_lshl_b32 %0, %0, %4\n\t"
         "s_bitset0_b32 %0, 31\n\t"
-        "s_lshl_b32 %14, %14, %4\n\t"
-        "s_orn2_b32 %1, 0x80000000, %14"
-        : "+s"(low), "+s"(high), "=&s"(sym), "=&s"(n1), "=&s"(n2), "=&s"(r1), "=&s"(off), "=&s"(rng), "=&s"(full), "=&s"(bb), "=&s"(bm),
-          "=&s"(tt), "=&s"(lo), "=&s"(hi), "=&s"(t0), "=&s"(w3), "=&s"(t1)
-        : "s"(s.code), "s"(wx), "s"(wy), "s"(wz), "s"(ww)
-        : "scc");
+        "s_lshl_b32 %7, %7, %4\n\t"
+        "s_orn2_b32 %1, 0x80000000, %7"
+        : "+s"(low), "=&s"(high), "=&s"(sym), "=&s"(n1), "=&s"(n2), "=&s"(lo), "=&s"(hi), "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(fl)
+        : "s"(r1), "v"(stv), "s"(off), "s"(L)
+        : "scc", "vcc");
+    const uint32_t code = s.code;
     s.low = low; s.high = high;
-    // n = n1 + n2 <= 18: a selected symbol has T[sym+1] - T[sym] >= 1 of 65536 (a zero-width entry is never selected: offset >= b and
-    // offset < b cannot both hold) and range > 2^30 before the step, so the new range is >= 2^14: low' and high' agree on at most 18
-    // leading bits, and every underflow bit halves what is left of that budget.  One 32-bit refill therefore always covers the read,
-    // whatever the stream holds.  The refill is branch-free: a conditional update of the reader state costs a dozen register copies.
     if (__builtin_expect(rd.pos >= rd.wbase + 256, 0)) rd.fetch_window();
     const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rd.win, (rd.pos - rd.wbase) >> 2);
     unsigned long long acc = rd.acc, bits, t64;
@@ -522,7 +464,7 @@ __device__ __forceinline__ int ac_decode_symbol8_fast(AcState &s, DevBits &rd, u
         : "s"(n1), "s"(n2), "s"((unsigned long long)w)
         : "scc");
     // code' = ((code << n) | bits) ^ (n2 ? TOP : 0), see above (n1 <= 31 and n2 <= 30: two 32-bit shifts)
-    s.code = (((s.code << n1) << n2) | (uint32_t)bits) ^ ((uint32_t)(n2 != 0) << 31);
+    s.code = (((code << n1) << n2) | (uint32_t)bits) ^ ((uint32_t)(n2 != 0) << 31);
     rd.acc = acc; rd.nacc = nacc; rd.pos = pos;
     return sym;
 }
@@ -550,7 +492,7 @@ __global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, 
     const int q = start + i;
     const int th = idx[q], tw = idx[q + HW], g = p - th - tw;
     const long nchw = (((long)b * G + g) * H + th) * W + tw;
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    uint4 r = make_uint4(0u, 0u, 0u, 0u), r2 = r;
     if (!(mask[nchw] < 0.5f)) {                                      // coder.cpp:79
         float v[9];
 #pragma unroll
@@ -560,9 +502,10 @@ __global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, 
                 v[net * 3 + c] = y[((long)(net * B + b) * (3 * G) + g * 3 + c) * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0];
         int T[9];
         gmm_cdf9(v, v + 3, v + 6, T);                                // 0 = T[0] < T[1] < ... < T[8] = 65536
-        r = dec_pack8(T);
+        dec_pack8(T, r, r2);
     }
-    tab[(long)b * tab_pitch + i] = r;
+    tab[((long)b * tab_pitch + i) * 2] = r;
+    tab[((long)b * tab_pitch + i) * 2 + 1] = r2;
 }
 
 // LINEAR (test hook lic360_devcoder_decode): symbols go to code_out[b*G + start + i] instead of the latent layouts
@@ -577,41 +520,53 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
     const long SK = (long)sk_rows * sk_pitch;
     AcDevState ds = state[b];
     AcState st;
-    st.low = ds.low; st.high = ds.high; st.code = ds.code; st.underflow = 0; st.error = 0;
+    // (the state goes through inline assembly with scalar-register operands: make sure it IS scalar)
+    auto sgpr = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    st.low = sgpr(ds.low); st.high = sgpr(ds.high); st.code = sgpr(ds.code); st.underflow = 0; st.error = 0;
     DevBits rd;
-    rd.buf = bytes + (long)b * cap; rd.len = dev_stream_len(nbytes[b], cap); rd.pos = ds.pos; rd.acc = ds.acc; rd.nacc = ds.nacc; rd.lane = lane;
+    rd.buf = bytes + (long)b * cap; rd.len = dev_stream_len(nbytes[b], cap); rd.pos = (int)sgpr((uint32_t)ds.pos);
+    rd.acc = ((unsigned long long)sgpr((uint32_t)(ds.acc >> 32)) << 32) | sgpr((uint32_t)ds.acc); rd.nacc = (int)sgpr((uint32_t)ds.nacc); rd.lane = lane;
     rd.fetch_window();
-    // the tables and scan positions of the NEXT group of 64 symbols are fetched before the serial chain of the current one
-    // runs, so that no memory latency sits between groups
-    auto load_tab = [&](int base) __attribute__((always_inline)) {
-        uint4 t = make_uint4(0u, 0u, 0u, 0u);
-        if (base + lane < len) t = tab[(long)b * tab_pitch + base + lane];
+    // Tables: eight VGPRs hold the 8 x 8 words of a group's 64 symbols (lane 8q + k of register r = word k of symbol 8r + q); a
+    // register is refilled with the next group's words as soon as its eight symbols are decoded, so that no memory latency sits
+    // between groups.  The scan positions of the next group are fetched before the serial chain of the current one runs.
+    const uint32_t *const tw32 = (const uint32_t *)(tab + (long)b * tab_pitch * 2);
+    auto load_tab = [&](int base, int r) __attribute__((always_inline)) {
+        uint32_t t = 0u;
+        if (base + 8 * r + (lane >> 3) < len) t = tw32[(long)(base + 8 * r) * 8 + lane];
         return t;
     };
     auto load_pos = [&](int base, int &th, int &tw) __attribute__((always_inline)) {
         th = tw = 0;
         if constexpr (!LINEAR) { if (base + lane < len) { th = idx[start + base + lane]; tw = idx[start + base + lane + HW]; } }
     };
-    uint4 tcur = load_tab(0);
+    uint32_t tv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tv[r] = load_tab(0, r);
     int th_cur, tw_cur;
     load_pos(0, th_cur, tw_cur);
     for (int base = 0; base < len; base += 64) {
         const bool live = base + lane < len;
-        const uint4 tnext = load_tab(base + 64);
         int th_next, tw_next;
         load_pos(base + 64, th_next, tw_next);
-        const bool coded = (tcur.x >> 16) != 0u;
-        unsigned long long todo = __ballot(coded);
         int symv = 0;
-        while (todo) {                                                  // the coded symbols of this group of 64, in order
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)tcur.x, j), wy = (uint32_t)__builtin_amdgcn_readlane((int)tcur.y, j);
-            const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)tcur.z, j), ww = (uint32_t)__builtin_amdgcn_readlane((int)tcur.w, j);
-            const int sym = ac_decode_symbol8_fast(st, rd, wx, wy, wz, ww);
-            // (lane j of symv <- sym; clang exposes no writelane builtin.  The s_nop covers the SALU-writes-m0 -> lane-select hazard)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(symv) : "s"(sym), "s"(j) : "m0");   // (two SGPR sources: the lane select goes through m0)
+        unsigned long long coded_m = 0;                                 // bit j: symbol j of the group is coded
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            // a coded symbol has T[7] != 0 (lane 8q + 7); its bit is moved to lane 8q
+            unsigned long long todo = (__ballot(tv[r] != 0u) >> 7) & 0x0101010101010101ull;
+            while (todo) {                                              // the coded symbols of this register, in order
+                const int L = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int sym = ac_decode_symbol8_v(st, rd, tv[r], L);
+                const int j = 8 * r + (L >> 3);
+                coded_m |= 1ull << j;
+                // (lane j of symv <- sym; clang exposes no writelane builtin; two SGPR sources: the lane select goes through m0, the s_nop covers its hazard)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(symv) : "s"(sym), "s"(j));
+            }
+            tv[r] = load_tab(base + 64, r);
         }
+        const bool coded = (coded_m >> lane) & 1ull;
         if (live) {
             if constexpr (LINEAR) code_out[(long)b * G + start + base + lane] = coded ? (float)symv : 0.0f;
             else {
@@ -620,7 +575,7 @@ __global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab,
                 code_out[(((long)b * G + g) * H + th) * W + tw] = coded ? (float)symv : 0.0f;
             }
         }
-        tcur = tnext; th_cur = th_next; tw_cur = tw_next;
+        th_cur = th_next; tw_cur = tw_next;
     }
     ac_state_check(st);
     if (lane == 0) {
@@ -704,7 +659,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     rc |= dmalloc(&c->d_state, B);
     for (int p = 0; p < c->P; ++p) c->tab_pitch = std::max(c->tab_pitch, c->h_plane_start[p + 1] - c->h_plane_start[p]);
     c->tab_pitch = (c->tab_pitch + 63) / 64 * 64;
-    rc |= dmalloc(&c->d_tab, B * (size_t)c->tab_pitch);
+    rc |= dmalloc(&c->d_tab, 2 * B * (size_t)c->tab_pitch);                 // two uint4 per symbol (dec_pack8)
     if (rc) return 1;
     // decode activations are only ever read where already written or with a zero weight; they must be finite
     HIP_TRY(hipMemset(c->e_x0, 0, (B * G * EPL + TAIL) * 4));
@@ -1161,7 +1116,10 @@ __global__ void k_test_tab8(const int *__restrict__ tables, const float *__restr
     const int *T = tables + (start + i) * 9;
     const bool coded = !mask || !(mask[start + i] < 0.5f);
     if (coded && ((T[1] | T[2] | T[3] | T[4] | T[5] | T[6] | T[7]) & ~0xffff)) atomicOr(&st->error, 64);   // inner entries must fit 16 bits
-    tab[i] = coded ? dec_pack8(T) : make_uint4(0u, 0u, 0u, 0u);
+    uint4 r = make_uint4(0u, 0u, 0u, 0u), r2 = r;
+    if (coded) dec_pack8(T, r, r2);
+    tab[2 * i] = r;
+    tab[2 * i + 1] = r2;
 }
 __global__ void k_test_tabn(const int *__restrict__ tables, int ncode, long start, int len, int *__restrict__ tab) {
     const int i = blockIdx.x, k = threadIdx.x;
@@ -1197,7 +1155,7 @@ LIC360_API int lic360_devcoder_decode(void *stream, const int *tables, int ncode
     AcDevState *st = nullptr;
     uint4 *tab8 = nullptr;
     int *tabn = nullptr;
-    if (dmalloc(&st, 1) || dmalloc(&tab8, (size_t)chunk) || dmalloc(&tabn, (size_t)chunk * IMP_TW)) return 1;
+    if (dmalloc(&st, 1) || dmalloc(&tab8, 2 * (size_t)chunk) || dmalloc(&tabn, (size_t)chunk * IMP_TW)) return 1;
     hipLaunchKernelGGL(k_dec_init, dim3(1), dim3(64), 0, s, bytes, cap, nbytes, st, 1);
     LAUNCH_CHECK();
     for (long start = 0; start < n; start += chunk) {
