@@ -98,6 +98,37 @@ def test_config1_full_latent_through_the_device_coder(lic, golden):
     assert err == 0 and np.array_equal(got.astype(np.int32), lab)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_full_range_recurrence_and_last_symbol(lic, seed):
+    """The corner cases of the scalar-assembly symbol steps (csrc/codec_fused.hip): with T[1] a power of two, every
+    symbol 0 coded while low = 0 and high = 2^32 - 1 leaves exactly that state, so range == 2^32 RECURS (the interval starts are then
+    T << 16 themselves, not the 32-bit product); symbol 7 ends at T[8] = 65536, which does not fit the 16-bit table words; tables
+    with entries one apart give the longest shift runs.  Device bytes == the oracle coder's bytes, and every symbol comes back."""
+    import oracle as orc
+    rng = np.random.default_rng(900 + seed)
+    n = 6000
+    tab = np.zeros((n, 9), np.int32)
+    kinds = rng.integers(0, 4, n)
+    for i in range(n):
+        if kinds[i] == 0:   tab[i] = [0, 1 << 15, 40000, 45000, 50000, 55000, 60000, 65000, 65536]     # T[1] = 2^15
+        elif kinds[i] == 1: tab[i] = [0, 1 << 14, 1 << 15, 3 << 14, 50000, 50001, 50002, 50003, 65536]  # powers of two + width-1 symbols
+        elif kinds[i] == 2: tab[i] = [0, 1, 2, 3, 4, 5, 6, 7, 65536]                                  # all the mass on the last symbol
+        else:               tab[i] = np.concatenate([[0], np.sort(rng.choice(np.arange(1, 65536), 7, replace=False)), [65536]])
+    lab = np.zeros(n, np.int32)
+    lab[n // 3:] = rng.integers(0, 8, n - n // 3)                     # a long run of zeros first (range stays 2^32), then everything
+    lab[rng.random(n) < 0.15] = 7
+    lab[:64] = 0
+    mask = None if seed == 0 else (rng.random(n) > 0.3).astype(np.float32)
+    e = orc.Encoder()
+    e.encode(tab, 8, lab, mask, n)
+    want = e.finish()
+    assert dev_encode(lic, tab, 8, lab, mask) == want
+    for chunk in (64, 1000):
+        got, err = dev_decode(lic, want, tab, 8, mask, n, chunk)
+        keep = np.ones(n, bool) if mask is None else mask > 0.5
+        assert err == 0 and np.array_equal(got[keep].astype(np.int32), lab[keep]) and np.all(got[~keep] == 0)
+
+
 def test_truncated_stream_and_oversized_length_are_flagged(lic, golden):
     tab, lab = golden["rand8_tables"], golden["rand8_labels"].astype(np.int32)
     want = golden["rand8_bytes"].tobytes()
