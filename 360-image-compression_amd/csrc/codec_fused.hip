@@ -854,20 +854,70 @@ __device__ __forceinline__ void imp_table(const float *__restrict__ y, long base
     lic360_softmax_cdf(lg, T, tmp, nsym, 65536.0f);
     lic360_cdf_fixup(T, nsym, 1);
 }
+// The same arithmetic, operation for operation (lic360_softmax_cdf + lic360_cdf_fixup variant 1 of lic360_exact_math.h), for a
+// compile-time alphabet: every array index is static, so logits, exponentials and the table live in registers.  With the run-time
+// alphabet of imp_table the three arrays are scratch memory, and a table kernel of 32 positions took 49 us (4.6 ms of a single
+// image's 22 ms importance decode).
+template <int NSYM>
+__device__ __forceinline__ void imp_table_t(const float *__restrict__ y, long base, long cstride, float (&T)[NSYM + 1]) {
+    const float total = 65536.0f;
+    float lg[NSYM], tmp[NSYM];
+#pragma unroll
+    for (int i = 0; i < NSYM; ++i) lg[i] = y[base + i * cstride];
+    float m = lg[0];
+#pragma unroll
+    for (int i = 1; i < NSYM; ++i) if (m < lg[i]) m = lg[i];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NSYM; ++i) { tmp[i] = lic360_expf(lg[i] - m); s += tmp[i]; }
+    T[0] = 0.0f;
+    const float dp = total / s;
+#pragma unroll
+    for (int i = 0; i < NSYM - 1; ++i) {
+        const float ts = T[i] + (float)(int)((double)(tmp[i] * dp) + 0.5);
+        T[i + 1] = ts < total ? ts : total;
+    }
+    T[NSYM] = total;
+    float bias = 0.0f, mval = 0.0f;
+    int midx = 0;
+#pragma unroll
+    for (int i = 0; i < NSYM; ++i) {
+        const float nxt = T[i + 1] + bias;
+        if (nxt <= T[i]) bias += 1.0f;
+        T[i + 1] += bias;
+        if (T[i + 1] - T[i] > mval) { mval = T[i + 1] - T[i]; midx = i; }
+    }
+    if (bias > 0.0f) {
+#pragma unroll
+        for (int i = 0; i < NSYM; ++i) if (i >= midx) T[i + 1] -= bias;
+    }
+}
+#define IMP_NSYM_FAST 49                                              // the alphabet of every LIC360 importance net (model_zoo.py)
+template <bool FAST>
 __global__ void k_imp_enc_tables(const float *__restrict__ y, const float *__restrict__ lv, const int *__restrict__ pidx, uint2 *__restrict__ rec,
                                  int B, int H, int W, int nsym) {
     const long HW = (long)H * W, total = HW * B;
     GRID_STRIDE(i, total) {
         const int tw = (int)(i % W), th = (int)((i / W) % H), b = (int)(i / HW), s = th + tw;
-        float T[65];
-        imp_table(y, (long)b * nsym * HW + (long)th * W + tw, HW, nsym, T);
         int sym = (int)lv[i];
         sym = sym < 0 ? 0 : (sym > nsym - 1 ? nsym - 1 : sym);
-        rec[(long)b * HW + pidx[s] + (th - (s >= W ? s - W + 1 : 0))] = make_uint2((unsigned)(int)T[sym], (unsigned)(int)T[sym + 1]);
+        unsigned lo = 0u, hi = 0u;
+        if constexpr (FAST) {
+            float T[IMP_NSYM_FAST + 1];
+            imp_table_t<IMP_NSYM_FAST>(y, (long)b * nsym * HW + (long)th * W + tw, HW, T);
+#pragma unroll
+            for (int k = 0; k < IMP_NSYM_FAST; ++k) if (k == sym) { lo = (unsigned)(int)T[k]; hi = (unsigned)(int)T[k + 1]; }
+        } else {
+            float T[65];
+            imp_table(y, (long)b * nsym * HW + (long)th * W + tw, HW, nsym, T);
+            lo = (unsigned)(int)T[sym]; hi = (unsigned)(int)T[sym + 1];
+        }
+        rec[(long)b * HW + pidx[s] + (th - (s >= W ? s - W + 1 : 0))] = make_uint2(lo, hi);
     }
 }
 // decode activations are diagonal-major [n][c][H+W-1][H] (cell (th, tw) at (th+tw)*H + th): the 16 plane positions a
 // conv wave gathers are contiguous
+template <bool FAST>
 __global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__ y, const int *__restrict__ idx, int start, int len,
                                                        int *__restrict__ tab, int tab_pitch, int H, int W, int nsym,
                                                        int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
@@ -875,10 +925,17 @@ __global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__
     if (i >= len) return;
     const long HW = (long)H * W, SK = (long)sk_rows * sk_pitch;
     const int th = idx[start + i], tw = idx[start + i + HW];
-    float T[65];
-    imp_table(y, (long)b * nsym * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0, SK, nsym, T);
     int *row = tab + ((long)b * tab_pitch + i) * IMP_TW;
-    for (int k = 0; k <= nsym; ++k) row[k] = (int)T[k];
+    if constexpr (FAST) {
+        float T[IMP_NSYM_FAST + 1];
+        imp_table_t<IMP_NSYM_FAST>(y, (long)b * nsym * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0, SK, T);
+#pragma unroll
+        for (int k = 0; k <= IMP_NSYM_FAST; ++k) row[k] = (int)T[k];
+    } else {
+        float T[65];
+        imp_table(y, (long)b * nsym * SK + (long)(th + tw + sk_row0) * sk_pitch + th + sk_col0, SK, nsym, T);
+        for (int k = 0; k <= nsym; ++k) row[k] = (int)T[k];
+    }
 }
 // one wave per image: lane k holds T[k] of the current symbol; the symbol is the number of inner entries <= target
 template <bool LINEAR>
@@ -1030,7 +1087,8 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
             float *tmp = cur; cur = nxt; nxt = tmp;
         }
         if (lic360_cconv144_ec(stream, c->plan[2], cur, c->packed144[11], c->bias[11], nullptr, nullptr, c->e_plain, B, H, W, (long)c->HW, W, 0)) return 1;
-        hipLaunchKernelGGL(k_imp_enc_tables, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, c->e_plain, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
+        if (c->nsym == IMP_NSYM_FAST) hipLaunchKernelGGL(k_imp_enc_tables<true>, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, c->e_plain, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
+        else hipLaunchKernelGGL(k_imp_enc_tables<false>, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, c->e_plain, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
         LAUNCH_CHECK();
@@ -1047,7 +1105,8 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (ec(11, cur, nullptr, t1)) return 1;                                         // [B, nsym, H, W] (uses the first nsym planes of the buffer)
-    hipLaunchKernelGGL(k_imp_enc_tables, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, t1, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
+    if (c->nsym == IMP_NSYM_FAST) hipLaunchKernelGGL(k_imp_enc_tables<true>, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, t1, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
+    else hipLaunchKernelGGL(k_imp_enc_tables<false>, dim3(lic360_blocks(total, 1)), dim3(64), 0, s, t1, levels, c->d_pidx, c->e_rec, B, H, W, c->nsym);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)c->HW, bytes, cap, nbytes, err);
     LAUNCH_CHECK();
@@ -1081,8 +1140,12 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
         if (dc(11, c->d_act[10], nullptr, c->d_y, p)) return 1;
         const int start = pih[p], len = pih[p + 1] - pih[p];
         if (len <= 0) continue;
-        hipLaunchKernelGGL(k_imp_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
-                           c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        if (c->nsym == IMP_NSYM_FAST)
+            hipLaunchKernelGGL(k_imp_dec_tables<true>, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
+                               c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        else
+            hipLaunchKernelGGL(k_imp_dec_tables<false>, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
+                               c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_imp_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
                            c->d_x0, levels_out, H, W, c->nsym, c->sc, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);

@@ -1,6 +1,8 @@
 """Importance-map stream of 512x1024 ERPs (32x64 maps, 144 hidden channels, 49 levels) through FusedImpCodec: timings."""
 import os, sys, time
-sys.path.insert(0, "360-image-compression_amd"); sys.path.insert(0, "oracle"); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("360-image-compression_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
 import torch, numpy as np
 import ref_codec as rc
 from lic360_fused import FusedImpCodec
