@@ -760,8 +760,8 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     return 0;
 }
 
-LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
-                                   const float *mask, int B, float *code_out, int *err) {
+static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
+                             const float *mask, int B, float *code_out, int *err, void *const *gate, int n_gate, int gate_stride) {
     if (check_ready(c, B)) return 2;
     ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -779,6 +779,7 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
         return lic360_cconv_dc_plane_ex(stream, pl, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3,
                                         c->d_idx, c->d_pidx, pih, p, x_mod, 1);
     };
+    int gate_q = -1;
     for (int p = 0; p < c->P; ++p) {
         // plane p of all 12 layers (x0 already holds planes < p)
         int rc = 0;
@@ -794,6 +795,10 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
         int start, len;
         lic360_plane_window(p, G, H, W, pih, &start, &len);
         if (len <= 0) continue;
+        if (gate) {                                                     // the mask of this plane's positions: map planes <= p / stride (see lic360_impcodec_decode_masked)
+            const int q = std::min(n_gate - 1, p / gate_stride);
+            if (q != gate_q) { HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)gate[q], 0)); gate_q = q; }
+        }
         PROF(c, PROF_DEC_TABLES, s, hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p,
                                                        c->d_tab, c->tab_pitch, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0));
         LAUNCH_CHECK();
@@ -805,6 +810,18 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
     LAUNCH_CHECK();
     return 0;
+}
+LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
+                                   const float *mask, int B, float *code_out, int *err) {
+    return codec_decode_impl(stream, c, bytes, cap, nbytes, mask, B, code_out, err, nullptr, 0, 1);
+}
+// The same decode behind an importance-map decode that runs on another stream and fills `mask` plane by plane
+// (lic360_impcodec_decode_masked): the convolutions of a latent plane need no mask at all, its table kernel waits for event
+// min(n_events - 1, plane / stride) before it reads the mask.  Results are those of lic360_codec_decode on the finished mask.
+LIC360_API int lic360_codec_decode_gated(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
+                                         const float *mask, int B, float *code_out, int *err, void *const *events, int n_events, int stride) {
+    ARG_CHECK(events && n_events > 0 && stride > 0);
+    return codec_decode_impl(stream, c, bytes, cap, nbytes, mask, B, code_out, err, events, n_events, stride);
 }
 
 // ------------------------------------------------------------------------------------------------ importance-map stream
@@ -833,6 +850,8 @@ struct lic360_impcodec {
     int *d_tab;                                 // [maxB][tab_pitch][IMP_TW] tables of the current plane
     int tab_pitch;
     AcDevState *d_state;
+    // lic360_impcodec_decode_masked: one event per plane ("the latent mask of every map cell of planes <= p is final")
+    std::vector<hipEvent_t> plane_ev;
 };
 #define IMP_TW 64                              // ints per table row (nsym + 1 <= 64), one per lane
 
@@ -1035,6 +1054,7 @@ LIC360_API void lic360_impcodec_destroy(lic360_impcodec *c) {
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0);
     for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
     (void)hipFree(c->d_y); (void)hipFree(c->d_tab); (void)hipFree(c->d_state);
+    for (hipEvent_t e : c->plane_ev) (void)hipEventDestroy(e);
     delete c;
 }
 LIC360_API int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int layer, const float *weight, const float *bias, const float *act) {
@@ -1112,8 +1132,23 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
     LAUNCH_CHECK();
     return 0;
 }
-LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
-                                      float *levels_out, int *err) {
+// mask_out cells of the map positions idx[start .. start+len): Dtow(stride)(Imp2mask(levels)) restricted to them --
+//   tmask(tc, th, tw) = tc < int(level + 1e-5) * cpn                                 (extension/imp2mask_cuda.cu:31)
+//   out(pc, ph, pw)   = tmask(pc s^2 + (ph % s) s + pw % s, ph / s, pw / s)          (extension/dtow_cuda.cu:38-56)
+__global__ void k_imp_mask_plane(const float *__restrict__ levels, const int *__restrict__ idx, int start, int len, float *__restrict__ out,
+                                 int B, int H, int W, int C, int s, int cpn) {
+    const long HW = (long)H * W, total = (long)B * len * C;
+    const int Co = C / (s * s), Ho = H * s, Wo = W * s;
+    GRID_STRIDE(e, total) {
+        const int tc = (int)(e % C), i = (int)((e / C) % len), b = (int)(e / C / len);
+        const int th = idx[start + i], tw = idx[start + i + HW];
+        const int imp = (int)((double)levels[(long)b * HW + (long)th * W + tw] + 1e-5) * cpn;
+        const int pc = tc / (s * s), r = tc % (s * s), ph = th * s + r / s, pw = tw * s + r % s;
+        out[(((long)b * Co + pc) * Ho + ph) * Wo + pw] = tc < imp ? 1.0f : 0.0f;
+    }
+}
+static int impcodec_decode_impl(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
+                                float *levels_out, int *err, float *mask_out, int mask_c, int stride) {
     if (imp_ready(c, B)) return 2;
     ARG_CHECK(bytes && nbytes && levels_out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
@@ -1150,10 +1185,41 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
         hipLaunchKernelGGL(k_imp_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
                            c->d_x0, levels_out, H, W, c->nsym, c->sc, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
         LAUNCH_CHECK();
+        if (mask_out) {
+            // the latent mask of the map cells decoded in this plane (cells of later planes hold whatever the buffer held: nobody
+            // reads their mask before their plane's event)
+            const long tot = (long)B * len * mask_c;
+            hipLaunchKernelGGL(k_imp_mask_plane, dim3(lic360_blocks(tot, 1)), dim3(256), 0, s, levels_out, c->d_idx, start, len, mask_out, B, H, W,
+                               mask_c, stride, mask_c / (c->nsym - 1));
+            LAUNCH_CHECK();
+            HIP_TRY(hipEventRecord(c->plane_ev[p], s));
+        }
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
     LAUNCH_CHECK();
     return 0;
+}
+LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
+                                      float *levels_out, int *err) {
+    return impcodec_decode_impl(stream, c, bytes, cap, nbytes, B, levels_out, err, nullptr, 0, 0);
+}
+// Decode + the latent codec's mask, plane by plane: after plane p of the maps, the cells of mask_out = Dtow(stride)(Imp2mask(levels_out))
+// (ImpEntDecoder.forward's last three lines, test/lic360_demo.py:283-287) that plane p decides are written and event p is recorded, so
+// that a latent decode on ANOTHER stream can run behind the map's decode instead of after it (lic360_codec_decode_gated): the latent
+// plane q only reads the mask of map cells (h >> 1, w >> 1) with h + w <= q, i.e. of map planes <= q / stride.
+// mask_out: [B][mask_c / stride^2][stride h][stride w]; events_out receives the codec-owned array of the P = h + w - 1 events.
+LIC360_API int lic360_impcodec_decode_masked(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
+                                             float *levels_out, int *err, float *mask_out, int mask_c, int stride, void ***events_out, int *n_events) {
+    ARG_CHECK(c && mask_out && events_out && n_events && mask_c > 0 && stride > 0 && mask_c % (stride * stride) == 0 && c->nsym > 1 &&
+              mask_c % (c->nsym - 1) == 0 && B > 0 && B <= c->maxB);
+    while ((int)c->plane_ev.size() < c->P) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));   // (same-device consumers only: no system-scope cache writeback per plane)
+        c->plane_ev.push_back(e);
+    }
+    *events_out = (void **)c->plane_ev.data();
+    *n_events = c->P;
+    return impcodec_decode_impl(stream, c, bytes, cap, nbytes, B, levels_out, err, mask_out, mask_c, stride);
 }
 
 // ------------------------------------------------------------------------------------------------ device-coder test hooks

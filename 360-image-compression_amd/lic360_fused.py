@@ -77,13 +77,20 @@ class FusedCodec(object):
                                       _p(self.nbytes), _p(self.err)))
         return b
 
-    def decode_async(self, mask, b=None, bytes_dev=None, nbytes_dev=None):
+    def decode_async(self, mask, b=None, bytes_dev=None, nbytes_dev=None, gate=None):
+        """gate: what FusedImpCodec.decode_masked_async returned -- `mask` is then being filled plane by plane on another stream
+        and every plane's table kernel waits for the event that covers it."""
         self._check(mask, "mask")
         b = mask.shape[0] if b is None else b
         bd = self.bytes if bytes_dev is None else bytes_dev
         nd = self.nbytes if nbytes_dev is None else nbytes_dev
-        _chk(_lib.lic360_codec_decode(_stream(self.device), self._h, _p(bd), C.c_long(bd.shape[1]), _p(nd), _p(mask), b,
-                                      _p(self.code_out), _p(self.err)))
+        if gate is None:
+            _chk(_lib.lic360_codec_decode(_stream(self.device), self._h, _p(bd), C.c_long(bd.shape[1]), _p(nd), _p(mask), b,
+                                          _p(self.code_out), _p(self.err)))
+        else:
+            ev, n, stride = gate
+            _chk(_lib.lic360_codec_decode_gated(_stream(self.device), self._h, _p(bd), C.c_long(bd.shape[1]), _p(nd), _p(mask), b,
+                                                _p(self.code_out), _p(self.err), ev, int(n), int(stride)))
         return self.code_out[:b]
 
     def encode(self, code, mask):
@@ -184,6 +191,20 @@ class FusedImpCodec(object):
         _chk(_lib.lic360_impcodec_decode(_stream(self.device), self._h, _p(self.bytes), C.c_long(self.cap), _p(self.nbytes), int(b),
                                          _p(self.levels_out), _p(self.err)))
         return self.levels_out[:b]
+
+    def decode_masked_async(self, b, mask_out, mask_channels=192, stride=2):
+        """decode_async + the latent codec's mask Dtow(stride)(Imp2mask(levels)) into `mask_out`
+        [b, mask_channels / stride^2, stride h, stride w], refreshed after every plane.  Returns the gate
+        (events, n_events, stride) to hand to FusedCodec.decode_async(..., gate=...) ON ANOTHER STREAM: the latent decode then
+        runs behind this one instead of after it (include/lic360_hip.h: lic360_impcodec_decode_masked)."""
+        want = (int(b), mask_channels // (stride * stride), stride * self.H, stride * self.W)
+        if not (mask_out.is_cuda and mask_out.dtype == torch.float32 and mask_out.is_contiguous() and tuple(mask_out.shape) == want):
+            raise Lic360Error("mask_out must be a contiguous float32 device tensor %s" % (want,))
+        ev, n = C.c_void_p(0), C.c_int(0)
+        _chk(_lib.lic360_impcodec_decode_masked(_stream(self.device), self._h, _p(self.bytes), C.c_long(self.cap), _p(self.nbytes), int(b),
+                                                _p(self.levels_out), _p(self.err), _p(mask_out), int(mask_channels), int(stride),
+                                                C.byref(ev), C.byref(n)))
+        return (ev, n.value, int(stride))
 
     def encode(self, levels):
         b = self.encode_async(levels)

@@ -32,6 +32,12 @@ import os
 import sys
 import time
 
+# Six HIP streams per rank (three sub-batches x {latent codec, importance-map codec}).  The HIP runtime multiplexes streams over 4
+# hardware queues by default: an importance stream that shares a queue with a latent stream runs behind that stream's long kernels,
+# and the latent decodes gated on it (lic360_codec_decode_gated) stall -- 49.3 instead of 50.6 Mpixel/s.  Must be set before the
+# runtime initialises; inherited by the ranks the supervisor spawns.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "360-image-compression_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
@@ -173,7 +179,7 @@ def run_rank(args):
     ns = max(1, min(args.streams, B))
     sizes = [B // ns + (1 if i < B % ns else 0) for i in range(ns)]
     code_np, mask_np, level_np = synth_latents(B, seed0=1000 * rank)
-    codecs, icodecs, codes, masks, levels, streams, istreams = [], [], [], [], [], [], []
+    codecs, icodecs, codes, masks, levels, streams, istreams, mbufs, mdone = [], [], [], [], [], [], [], [], []
     o = 0
     for sz in sizes:
         c = FusedCodec(G, H, W, max_batch=sz, device=local)
@@ -189,8 +195,12 @@ def run_rank(args):
         # the importance-map codec of a sub-batch runs on a stream of its own: the two bitstreams of an image are independent,
         # and its small kernels fill the gaps the latent codec's launches leave
         istreams.append(torch.cuda.Stream(device=dev) if args.imp_streams else streams[-1])
+        mbufs.append([torch.zeros((sz, G, H, W), dtype=torch.float32, device=dev) for _ in range(2)])   # the masks the importance decode derives on the device
+        mdone.append([torch.cuda.Event(), torch.cuda.Event()])
         o += sz
     torch.cuda.synchronize(dev)
+
+    flip, last_mb = [0], {}
 
     def run(cds, mks, lvs, imp=True):
         """encode then decode of one list of sub-batches (one per stream); inputs resident in HBM, bitstreams stay in HBM"""
@@ -201,13 +211,31 @@ def run_rank(args):
                         ic.encode_async(lv)
                 with torch.cuda.stream(st):
                     c.encode_async(cd, mk)
-        for c, ic, cd, mk, lv, st, ist in zip(codecs, icodecs, cds, mks, lvs, streams, istreams):
-            if cd.shape[0]:
-                if imp:
-                    with torch.cuda.stream(ist):
-                        ic.decode_async(lv.shape[0])
+        flip[0] ^= 1
+        for c, ic, cd, mk, lv, st, ist, mb2, ev2 in zip(codecs, icodecs, cds, mks, lvs, streams, istreams, mbufs, mdone):
+            mb, ev = mb2[flip[0]], ev2[flip[0]]                             # two mask buffers per codec: the map decode of one step does not
+            last_mb[id(c)] = mb                                             # wait for the latent decode of the step before
+            n = cd.shape[0]
+            if not n:
+                continue
+            if not imp:
                 with torch.cuda.stream(st):
-                    c.decode_async(mk, cd.shape[0])
+                    c.decode_async(mk, n)
+                continue
+            # the decoder's own data flow (test/lic360_demo.py:283-287, 218-238): the latent's mask is what the DECODED importance map
+            # says.  The map decodes on its stream and writes the mask plane by plane; the latent decode runs behind it, each plane's
+            # table kernel waiting for the event that covers its positions (lic360_codec_decode_gated).
+            if ist is st:
+                with torch.cuda.stream(st):
+                    ic.decode_masked_async(n, mb[:n])                        # one stream: plain order, mask from the finished map
+                    c.decode_async(mb[:n], n)
+            else:
+                ist.wait_event(ev)                                           # the previous latent decode may still be reading the mask buffer
+                with torch.cuda.stream(ist):
+                    gate = ic.decode_masked_async(n, mb[:n])
+                with torch.cuda.stream(st):
+                    c.decode_async(mb[:n], n, gate=gate)
+                    ev.record(st)
 
     def exact(cds, mks, lvs, imp=True):
         ok = True
@@ -215,9 +243,10 @@ def run_rank(args):
             n = cd.shape[0]
             if not n:
                 continue
+            mb = last_mb.get(id(c))
             ok = ok and bool(torch.equal(c.code_out[:n], cd * mk)) and int(c.err[:n].abs().sum().item()) == 0
-            if imp:
-                ok = ok and bool(torch.equal(ic.levels_out[:n], lv)) and int(ic.err[:n].abs().sum().item()) == 0
+            if imp:                                                          # ... and the mask the device derived from the decoded map is the encoder's
+                ok = ok and bool(torch.equal(ic.levels_out[:n], lv)) and int(ic.err[:n].abs().sum().item()) == 0 and mb is not None and bool(torch.equal(mb[:n], mk))
         return ok
 
     step = lambda: run(codes, masks, levels, True)
@@ -288,16 +317,30 @@ def run_rank(args):
         except Exception as e:                                         # noqa: BLE001  (never lose the headline to a side figure)
             err5 = repr(e)[:300]
         if shard.all_ok(err5 is None, dev):
+            mb5 = [torch.zeros_like(m) for m in mk5]                         # decode side: the mask comes from the decoded map (see run())
+            ev5 = [torch.cuda.Event() for _ in mk5]
             def run5():
-                for ph in (0, 1):
-                    for c, ic, a, b_, l_, st, ist in zip(c5, i5, cd5, mk5, lv5, streams, istreams):
-                        with torch.cuda.stream(ist):
-                            ic.encode_async(l_) if ph == 0 else ic.decode_async(B5)
+                for c, ic, a, b_, l_, st, ist in zip(c5, i5, cd5, mk5, lv5, streams, istreams):
+                    with torch.cuda.stream(ist):
+                        ic.encode_async(l_)
+                    with torch.cuda.stream(st):
+                        c.encode_async(a, b_)
+                for c, ic, st, ist, mb, ev in zip(c5, i5, streams, istreams, mb5, ev5):
+                    if ist is st:
                         with torch.cuda.stream(st):
-                            c.encode_async(a, b_) if ph == 0 else c.decode_async(b_, B5)
+                            ic.decode_masked_async(B5, mb)
+                            c.decode_async(mb, B5)
+                    else:
+                        ist.wait_event(ev)
+                        with torch.cuda.stream(ist):
+                            gate = ic.decode_masked_async(B5, mb)
+                        with torch.cuda.stream(st):
+                            c.decode_async(mb, B5, gate=gate)
+                            ev.record(st)
             run5()
             dt5 = shard.timed(run5, 2, dev)
             ok5 = all(bool(torch.equal(c.code_out[:B5], a * b_)) and int(c.err[:B5].abs().sum().item()) == 0 for c, a, b_ in zip(c5, cd5, mk5))
+            ok5 = ok5 and all(bool(torch.equal(mb, m)) for mb, m in zip(mb5, mk5))
             ok5 = ok5 and all(bool(torch.equal(ic.levels_out[:B5], l_)) and int(ic.err[:B5].abs().sum().item()) == 0 for ic, l_ in zip(i5, lv5))
             ok = ok and ok5
             extras["config5"] = {"images_per_gpu": B5 * ns, "ms": dt5 / 2 * 1e3, "value": world * B5 * ns * 4 * PIXELS / (dt5 / 2) / 1e6, "unit": "Mpixel/s",
@@ -306,6 +349,7 @@ def run_rank(args):
         else:
             extras["config5"] = {"error": err5 or "set-up failed on another rank"}
         del c5, i5, cd5, mk5, lv5
+        mb5 = None
         torch.cuda.empty_cache()
     ok = shard.all_ok(ok, dev)
 
@@ -325,7 +369,7 @@ def run_rank(args):
         out["config"].update(extras)
         out.update(instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B))
         if world == 1 and not args.no_extras:
-            out["config"]["single_image"] = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], dev)
+            out["config"]["single_image"] = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], istreams[0], mbufs[0][0], dev)
             try:
                 import stream_ops_bench
                 rows = stream_ops_bench.measure(batches=(32,), device=local)
@@ -347,24 +391,47 @@ def run_rank(args):
     return 0
 
 
-def single_image(c, ic, code, mask, lv, st, dev):
-    """BASELINE.json configs[1] / [2]: one 512x1024 image alone on the GPU -- encode latency, decode latency (both streams)."""
+def single_image(c, ic, code, mask, lv, st, ist, mb, dev):
+    """BASELINE.json configs[1] / [2]: one 512x1024 image alone on the GPU -- encode latency, decode latency (both streams).
+    Encode: the two bitstreams are independent (two HIP streams).  Decode: the latent's mask is derived on the device from the decoded
+    importance map; the latent decode runs behind the map's decode, gated plane by plane (lic360_codec_decode_gated)."""
     import torch
     res = {}
-    with torch.cuda.stream(st):
-        for name, fn in (("encode_ms", lambda: (ic.encode_async(lv[:1]), c.encode_async(code[:1], mask[:1]))),
-                         ("decode_ms", lambda: (ic.decode_async(1), c.decode_async(mask[:1], 1)))):
+    ev = torch.cuda.Event()
+
+    def enc():
+        ist.wait_stream(st)
+        with torch.cuda.stream(ist):
+            ic.encode_async(lv[:1])
+        with torch.cuda.stream(st):
+            c.encode_async(code[:1], mask[:1])
+            st.wait_stream(ist)
+
+    def dec():
+        if ist is st:
+            with torch.cuda.stream(st):
+                ic.decode_masked_async(1, mb[:1])
+                c.decode_async(mb[:1], 1)
+            return
+        ist.wait_stream(st)                                                  # one image after the other: this measures a latency
+        with torch.cuda.stream(ist):
+            gate = ic.decode_masked_async(1, mb[:1])
+        with torch.cuda.stream(st):
+            c.decode_async(mb[:1], 1, gate=gate)
+            st.wait_stream(ist)
+
+    for name, fn in (("encode_ms", enc), ("decode_ms", dec)):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
             fn()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize(dev)
-            res[name] = (time.perf_counter() - t0) / 3 * 1e3
-    res["roundtrip_exact"] = bool(torch.equal(c.code_out[:1], code[:1] * mask[:1]) and torch.equal(ic.levels_out[:1], lv[:1]))
+        torch.cuda.synchronize(dev)
+        res[name] = (time.perf_counter() - t0) / 3 * 1e3
+    res["roundtrip_exact"] = bool(torch.equal(c.code_out[:1], code[:1] * mask[:1]) and torch.equal(ic.levels_out[:1], lv[:1]) and torch.equal(mb[:1], mask[:1]))
     res["value"] = PIXELS / ((res["encode_ms"] + res["decode_ms"]) * 1e-3) / 1e6
     res["unit"] = "Mpixel/s"
-    res["note"] = "configs[1]/[2]: latency-bound (238 dependent planes x 14 launches, one serial coder chain)"
+    res["note"] = "configs[1]/[2]: latency-bound (238 dependent planes x 14 launches, one serial coder chain); decode: mask from the decoded importance map, latent decode gated behind the map's"
     return res
 
 

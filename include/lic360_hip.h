@@ -269,6 +269,12 @@ int lic360_codec_encode(void *stream, lic360_codec *codec, const float *code, co
 /* bitstreams + mask -> code_out [b,ngroup,h,w] (decoded symbol where mask, 0 elsewhere: `b[0:1] + 3.5*mask`, lic360_demo.py:236-237) */
 int lic360_codec_decode(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
                         const float *mask, int b, float *code_out, int *err);
+/* lic360_codec_decode behind a map decode that fills `mask` on another stream (lic360_impcodec_decode_masked): the convolutions of
+ * a latent plane read no mask; the plane's table kernel waits for events[min(n_events - 1, plane / stride)].  Same results as
+ * lic360_codec_decode on the finished mask.  No reference counterpart: DcEntDecoder.forward takes the finished mask
+ * (test/lic360_demo.py:218-238); this only moves the 18 ms of a map's decode under the 97 ms of the latent's. */
+int lic360_codec_decode_gated(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
+                              const float *mask, int b, float *code_out, int *err, void *const *events, int n_events, int stride);
 
 /* Device-resident importance-map stream (ImpEntEncoderFast / ImpEntDecoder, test/lic360_demo.py:143-189, 241-290): one
  * group, 12 spatially causal layers with `hidden_channels` channels, nsym-way softmax tables (entropy_table_cuda.cu:24-96),
@@ -280,6 +286,12 @@ void lic360_impcodec_destroy(lic360_impcodec *c);
 int lic360_impcodec_set_layer(void *stream, lic360_impcodec *c, int layer, const float *weight, const float *bias, const float *act);
 int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const float *levels, int B, uint8_t *bytes, long cap, int *nbytes, int *err);
 int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B, float *levels_out, int *err);
+/* The map's decode AND the latent codec's mask, plane by plane: after plane p, mask_out = Dtow(stride)(Imp2mask(levels_out)) -- the
+ * last three lines of ImpEntDecoder.forward (test/lic360_demo.py:283-287) -- is refreshed and the codec-owned event p is recorded,
+ * so that lic360_codec_decode_gated on ANOTHER stream runs behind the map's decode instead of after it.  mask_out:
+ * [B][mask_c / stride^2][stride h][stride w] (LIC360: mask_c = 192, stride = 2); *events_out / *n_events: the h + w - 1 events. */
+int lic360_impcodec_decode_masked(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
+                                  float *levels_out, int *err, float *mask_out, int mask_c, int stride, void ***events_out, int *n_events);
 
 /* ---- f3 viewport projection (ProjectsOp, the sampling stage of VPSNR / VSSIM) -------------------------------------------------
  * Sampling coordinates tf [14][h_out*w_out][2] = (x, y) in ERP pixels of the 14 rectilinear viewports (yaw theta*pi, pitch phi*pi, field

@@ -186,6 +186,45 @@ def test_fused_importance_codec_matches_oracle(cpg, nsym, H, W, B, seed):
     assert np.array_equal(rc.decode_imp(streams[0], layers, H, W, nsym), levels[0:1])
 
 
+@pytest.mark.parametrize("G,MH,MW,B,seed", [(12, 8, 12, 1, 71), (12, 8, 12, 3, 72), (24, 6, 10, 2, 73)])
+def test_latent_decode_gated_behind_the_map_decode(G, MH, MW, B, seed):
+    """lic360_impcodec_decode_masked + lic360_codec_decode_gated: the importance map decodes on one stream and refreshes the latent
+    codec's mask after every plane (Dtow(2)(Imp2mask(levels)), lic360_demo.py:283-287), the latent decodes on ANOTHER stream and
+    every plane's table kernel waits for the event that covers its positions.  The mask the device derives == the oracle ops'
+    mask of the true levels, and the latent comes back exactly -- also when the mask buffer starts out as garbage."""
+    import oracle as orc
+    from lic360_fused import FusedCodec, FusedImpCodec
+    rng = np.random.default_rng(seed)
+    nsym, H, W = 49, 2 * MH, 2 * MW
+    levels = rng.integers(0, nsym, (B, 1, MH, MW)).astype(np.float32)
+    mask = orc.dtow(orc.imp2mask(levels, nsym - 1, 4 * G), 2, True)            # [B, G, H, W]
+    assert mask.shape == (B, G, H, W) and 0.05 < mask.mean() < 0.95
+    code = np.clip(np.rint(rng.normal(3.5, 1.2, (B, G, H, W))), 0, 7).astype(np.float32)
+    ic = FusedImpCodec(MH, MW, max_batch=B, hidden_channels=8, nsym=nsym)
+    ic.load_layers(rc.make_imp_params(4000 + seed, 8, nsym))
+    fc = FusedCodec(G, H, W, max_batch=B)
+    fc.load_layers(rc.make_main_params(2000 + seed, G))
+    ic.encode_async(dev(levels))
+    fc.encode_async(dev(code), dev(mask))
+    torch.cuda.synchronize()
+    assert int(ic.err[:B].abs().sum().item()) == 0 and int(fc.err[:B].abs().sum().item()) == 0
+    s_map, s_lat = torch.cuda.Stream(), torch.cuda.Stream()
+    mbuf = torch.full((B, G, H, W), 7.0, dtype=torch.float32, device="cuda:0")   # garbage: a mask read too early would show
+    for _ in range(2):
+        ic.levels_out.fill_(48.0)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_map):
+            gate = ic.decode_masked_async(B, mbuf, mask_channels=4 * G, stride=2)     # (records its events before the waits below are queued)
+        with torch.cuda.stream(s_lat):
+            out = fc.decode_async(mbuf, B, gate=gate)
+        torch.cuda.synchronize()
+        assert int(ic.err[:B].abs().sum().item()) == 0 and int(fc.err[:B].abs().sum().item()) == 0
+        assert np.array_equal(ic.levels_out[:B].cpu().numpy(), levels)
+        assert np.array_equal(mbuf.cpu().numpy(), mask)
+        assert np.array_equal(out.cpu().numpy(), code * mask)
+        mbuf.fill_(7.0)
+
+
 def test_fused_codec_corrupt_stream_is_reported_not_fatal():
     """A truncated / damaged bitstream must end in an error (or a wrong-but-finite decode), never in a hang or a fault:
     the device decoder reads zeros past the end of a stream, like the reference's BitInputStream."""
