@@ -873,43 +873,13 @@ __device__ __forceinline__ void imp_table(const float *__restrict__ y, long base
     lic360_softmax_cdf(lg, T, tmp, nsym, 65536.0f);
     lic360_cdf_fixup(T, nsym, 1);
 }
-// The same arithmetic, operation for operation (lic360_softmax_cdf + lic360_cdf_fixup variant 1 of lic360_exact_math.h), for a
-// compile-time alphabet: every array index is static, so logits, exponentials and the table live in registers.  With the run-time
-// alphabet of imp_table the three arrays are scratch memory, and a table kernel of 32 positions took 49 us (4.6 ms of a single
-// image's 22 ms importance decode).
+// The same table for the compile-time alphabet of every LIC360 importance net: static indices, registers (gmm_tables.h)
 template <int NSYM>
 __device__ __forceinline__ void imp_table_t(const float *__restrict__ y, long base, long cstride, float (&T)[NSYM + 1]) {
-    const float total = 65536.0f;
-    float lg[NSYM], tmp[NSYM];
+    float lg[NSYM];
 #pragma unroll
     for (int i = 0; i < NSYM; ++i) lg[i] = y[base + i * cstride];
-    float m = lg[0];
-#pragma unroll
-    for (int i = 1; i < NSYM; ++i) if (m < lg[i]) m = lg[i];
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NSYM; ++i) { tmp[i] = lic360_expf(lg[i] - m); s += tmp[i]; }
-    T[0] = 0.0f;
-    const float dp = total / s;
-#pragma unroll
-    for (int i = 0; i < NSYM - 1; ++i) {
-        const float ts = T[i] + (float)(int)((double)(tmp[i] * dp) + 0.5);
-        T[i + 1] = ts < total ? ts : total;
-    }
-    T[NSYM] = total;
-    float bias = 0.0f, mval = 0.0f;
-    int midx = 0;
-#pragma unroll
-    for (int i = 0; i < NSYM; ++i) {
-        const float nxt = T[i + 1] + bias;
-        if (nxt <= T[i]) bias += 1.0f;
-        T[i + 1] += bias;
-        if (T[i + 1] - T[i] > mval) { mval = T[i + 1] - T[i]; midx = i; }
-    }
-    if (bias > 0.0f) {
-#pragma unroll
-        for (int i = 0; i < NSYM; ++i) if (i >= midx) T[i + 1] -= bias;
-    }
+    softmax_table_static<NSYM>(lg, 65536.0f, T);
 }
 #define IMP_NSYM_FAST 49                                              // the alphabet of every LIC360 importance net (model_zoo.py)
 template <bool FAST>

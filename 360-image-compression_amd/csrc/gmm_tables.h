@@ -19,3 +19,39 @@ __device__ __forceinline__ void gmm_cdf9(const float *lw_in, const float *ld_in,
     for (int pt = 0; pt < 9; ++pt) T[pt] = (int)t[pt];
 }
 
+
+// N-way softmax CDF + monotonic fix-up (entropy_table_cuda.cu:24-76) for a COMPILE-TIME alphabet: the same operations in the same
+// order as lic360_softmax_cdf + lic360_cdf_fixup(.., 1) of lic360_exact_math.h, with every array index static, so that logits,
+// exponentials and the table live in registers.  (With a run-time alphabet the per-thread arrays are scratch memory: a table kernel
+// of 32 positions took 49 us.)
+template <int NSYM>
+__device__ __forceinline__ void softmax_table_static(const float (&lg)[NSYM], float total, float (&T)[NSYM + 1]) {
+    float tmp[NSYM];
+    float m = lg[0];
+#pragma unroll
+    for (int i = 1; i < NSYM; ++i) if (m < lg[i]) m = lg[i];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NSYM; ++i) { tmp[i] = lic360_expf(lg[i] - m); s += tmp[i]; }
+    T[0] = 0.0f;
+    const float dp = total / s;
+#pragma unroll
+    for (int i = 0; i < NSYM - 1; ++i) {
+        const float ts = T[i] + (float)(int)((double)(tmp[i] * dp) + 0.5);
+        T[i + 1] = ts < total ? ts : total;
+    }
+    T[NSYM] = total;
+    float bias = 0.0f, mval = 0.0f;
+    int midx = 0;
+#pragma unroll
+    for (int i = 0; i < NSYM; ++i) {
+        const float nxt = T[i + 1] + bias;
+        if (nxt <= T[i]) bias += 1.0f;
+        T[i + 1] += bias;
+        if (T[i + 1] - T[i] > mval) { mval = T[i + 1] - T[i]; midx = i; }
+    }
+    if (bias > 0.0f) {
+#pragma unroll
+        for (int i = 0; i < NSYM; ++i) if (i >= midx) T[i + 1] -= bias;
+    }
+}

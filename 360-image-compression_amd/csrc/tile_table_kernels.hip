@@ -6,6 +6,7 @@
 // (the reference runs 4 kernels that round-trip the parameters through memory,
 // extension/entropy_gmm_table_cuda.cu:161-191).  Arithmetic comes from lic360_exact_math.h.
 #include "common.h"
+#include "gmm_tables.h"
 #include "lic360_exact_math.h"
 
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
@@ -171,10 +172,23 @@ __global__ void k_entropy_table(const float *__restrict__ logits, float *__restr
         for (int i = 0; i <= nstep; ++i) out[n * (nstep + 1) + i] = T[i];
     }
 }
+// the alphabet of the LIC360 importance nets at compile time (registers instead of scratch memory, see gmm_tables.h)
+template <int NSTEP>
+__global__ void k_entropy_table_static(const float *__restrict__ logits, float *__restrict__ out, int count, float total) {
+    GRID_STRIDE(n, count) {
+        float lg[NSTEP], T[NSTEP + 1];
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) lg[i] = logits[n * NSTEP + i];
+        softmax_table_static<NSTEP>(lg, total, T);
+#pragma unroll
+        for (int i = 0; i <= NSTEP; ++i) out[n * (NSTEP + 1) + i] = T[i];
+    }
+}
 LIC360_API int lic360_entropy_table(void *stream, const float *logits, float *out, int count, int nstep, float total) {
     ARG_CHECK(logits && out && count >= 0 && nstep >= 1 && nstep <= 64);
     if (count == 0) return 0;
-    hipLaunchKernelGGL(k_entropy_table, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, logits, out, count, nstep, total);
+    if (nstep == 49) hipLaunchKernelGGL(k_entropy_table_static<49>, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, logits, out, count, total);
+    else hipLaunchKernelGGL(k_entropy_table, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, logits, out, count, nstep, total);
     LAUNCH_CHECK();
     return 0;
 }
