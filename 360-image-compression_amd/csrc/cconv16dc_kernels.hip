@@ -345,6 +345,7 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
         auto body = [&](auto NN, auto NX, gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
             constexpr int N = decltype(NN)::value, NEXT = decltype(NX)::value;   // NEXT: diagonals the following block's body runs
             constexpr int NA = NEXT < XD_RA ? NEXT : XD_RA, NB = NEXT < XD_RB ? NEXT : XD_RB;     // slots it expects filled
+#ifndef XD_INTERLEAVE
             static_for<N>([&](auto dd) {
                 constexpr int dc = decltype(dd)::value, la = dc % XD_RA, lb = dc % XD_RB;
                 fma(dd, sa[la], sb[lb]);
@@ -352,6 +353,37 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
                 if constexpr (dc + XD_RA < N) loadA(IC<dc + XD_RA>{}, sa[la], wk); else if constexpr (la < NA) loadA(IC<la>{}, sa[la], wk1);
                 __builtin_amdgcn_sched_barrier(0);
             });
+#else
+            // experiment (tools/xd_lone.sh): the refill of a diagonal's operand slots is issued BETWEEN the first MFMAs of the following
+            // diagonal, one load group behind each -- ~3 instructions hide in the 32-cycle shadow of an MFMA, nine in a row after the
+            // last MFMA of a diagonal do not (tools/micro/mfma_issue.hip).  No effect with two waves per SIMD (116.3-119.5 us against 116.8).
+            auto refillB = [&](auto dd) __attribute__((always_inline)) {
+                constexpr int d = decltype(dd)::value, lb = d % XD_RB;
+                if constexpr (d + XD_RB < N) loadB(IC<d + XD_RB>{}, sb[lb], xk); else if constexpr (lb < NB) loadB(IC<lb>{}, sb[lb], xk1);
+            };
+            auto refillA = [&](auto dd) __attribute__((always_inline)) {
+                constexpr int d = decltype(dd)::value, la = d % XD_RA;
+                if constexpr (d + XD_RA < N) loadA(IC<d + XD_RA>{}, sa[la], wk); else if constexpr (la < NA) loadA(IC<la>{}, sa[la], wk1);
+            };
+            static_for<N>([&](auto dd) {
+                constexpr int dc = decltype(dd)::value, la = dc % XD_RA, lb = dc % XD_RB, T = xd_ntiles(dc), tb = xd_tbase(dc);
+                acc[tb][0] = xd_mfma(sa[la].a[0], sb[lb].x, acc[tb][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (dc >= 1) refillB(IC<(dc >= 1 ? dc - 1 : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+                acc[tb][1] = xd_mfma(sa[la].a[0], sb[lb].y, acc[tb][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (dc >= 1) refillA(IC<(dc >= 1 ? dc - 1 : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 1; t < T; ++t) {
+                    acc[tb + t][0] = xd_mfma(sa[la].a[t], sb[lb].x, acc[tb + t][0]);
+                    acc[tb + t][1] = xd_mfma(sa[la].a[t], sb[lb].y, acc[tb + t][1]);
+                }
+                if constexpr (dc == N - 1) { __builtin_amdgcn_sched_barrier(0); refillB(IC<N - 1>{}); refillA(IC<N - 1>{}); }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#endif
         };
         auto fill = [&](const Task &t) __attribute__((always_inline)) {       // operands of block 0, the first diagonals (rows always exist)
             static_for<XD_RB>([&](auto ss) { loadB(ss, sb[decltype(ss)::value], (gptr)t.xs); });
