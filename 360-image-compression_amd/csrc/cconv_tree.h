@@ -8,13 +8,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the reference's reduction tree on registers: F(i, 128) = p[i];  F(i, s) = F(i, 2s) + F(i + s, 2s);  result F(0, 1)
 // (p[i] + p[i+64] first, ..., + p[i+1] last; cconv_ec_cuda.cu:299-309).  A wave of class c evaluates F(c, 4).
 // Lane i of class c = i%4 lives in accumulator i%25 (cin = 4) or i/4 (cin = 1).
+// a + b of two accumulator quads as TWO v_pk_add_f32 (each: two independent IEEE fp32 adds, full rate on gfx90a+).  Written as
+// inline assembly because hipcc scalarises the whole tree into four per-component chains of v_add_f32 when its result is consumed
+// element by element -- twice the vector-ALU instructions in a phase where no MFMA runs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
+#ifdef LIC360_TREE_SCALAR
+    return a + b;
+#else
+    f32x2 lo, hi;
+    const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+#endif
+}
 template <int CIN, int I, int S>
 struct Tree4 {
     static constexpr bool live = Tree4<CIN, I, S * 2>::live || Tree4<CIN, I + S, S * 2>::live;
     static __device__ __forceinline__ f32x4 eval(const f32x4 *acc) {
         if constexpr (!Tree4<CIN, I + S, S * 2>::live) return Tree4<CIN, I, S * 2>::eval(acc);     // x + 0 == x
         else if constexpr (!Tree4<CIN, I, S * 2>::live) return Tree4<CIN, I + S, S * 2>::eval(acc);
-        else return Tree4<CIN, I, S * 2>::eval(acc) + Tree4<CIN, I + S, S * 2>::eval(acc);
+        else return pk_add4(Tree4<CIN, I, S * 2>::eval(acc), Tree4<CIN, I + S, S * 2>::eval(acc));
     }
 };
 template <int CIN, int I>
