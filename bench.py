@@ -489,10 +489,13 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
     dom = max(convs, key=lambda r: r["total_ms"])
     # fabric-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh;
     # Infinity-Cache hits are counted), scaled to this run's images per launch
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-    except Exception:                                              # noqa: BLE001
-        pmc = {}
+    pmc = {}
+    for tag in ("r03", "r02"):                                        # the newest committed collection
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
+            break
+        except Exception:                                          # noqa: BLE001
+            pass
     for r in rows:
         pm = pmc.get(r["kernel"])
         if isinstance(pm, dict):
