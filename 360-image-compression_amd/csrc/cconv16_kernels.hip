@@ -452,7 +452,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
 #endif
 #pragma unroll
             for (int t = 0; t < C16_NT; ++t) {
-                const f32x4 part = Tree4<CIN, CLS, 4>::eval(acc[t]);
+                const f32x4 part = tree4_eval<CIN, CLS>(acc[t]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) comb[(FUSE ? 0 : (ntile & 1)) * C16_COMB + (((PS * C16_NT + t) * 4 + CLS) * 4 + r) * 64 + lane] = part[r];
                 if constexpr (CIN == 1) {

@@ -165,7 +165,7 @@ __device__ __forceinline__ f32x4 ec4_body(const float *__restrict__ xn, const f3
         if (tc + 1 < Lmax) lstore(cur ^ 1);
         __syncthreads();
     }
-    return Tree4<CIN, CLS, 4>::eval(acc);
+    return tree4_eval<CIN, CLS>(acc);
 }
 
 template <int CIN>

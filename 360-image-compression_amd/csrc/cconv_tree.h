@@ -18,8 +18,8 @@ __device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
 #else
     f32x2 lo, hi;
     const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));   // (volatile: stays behind tree4_eval's wait states)
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
     return (f32x4){lo[0], lo[1], hi[0], hi[1]};
 #endif
 }
@@ -40,6 +40,17 @@ struct Tree4<CIN, I, 128> {
         else return (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 };
+
+// The tree's adds are inline assembly: hipcc's hazard recognizer does not see that they read MFMA results ("XDL write VGPR -> VALU
+// read" needs up to 18 wait states on gfx950), so every evaluation starts behind a fence no instruction may be scheduled across and
+// 32 wait states.  Two instructions per tile / task.
+template <int CIN, int CLS>
+__device__ __forceinline__ f32x4 tree4_eval(const f32x4 *acc) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+    return Tree4<CIN, CLS, 4>::eval(acc);
+}
 
 template <int CIN> struct NAcc { static constexpr int value = CIN == 4 ? 25 : 7; };
 
