@@ -8,28 +8,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the reference's reduction tree on registers: F(i, 128) = p[i];  F(i, s) = F(i, 2s) + F(i + s, 2s);  result F(0, 1)
 // (p[i] + p[i+64] first, ..., + p[i+1] last; cconv_ec_cuda.cu:299-309).  A wave of class c evaluates F(c, 4).
 // Lane i of class c = i%4 lives in accumulator i%25 (cin = 4) or i/4 (cin = 1).
-// a + b of two accumulator quads as TWO v_pk_add_f32 (each: two independent IEEE fp32 adds, full rate on gfx90a+).  Written as
-// inline assembly because hipcc scalarises the whole tree into four per-component chains of v_add_f32 when its result is consumed
-// element by element -- twice the vector-ALU instructions in a phase where no MFMA runs.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 pk_add4(f32x4 a, f32x4 b) {
-#ifdef LIC360_TREE_SCALAR
-    return a + b;
-#else
-    f32x2 lo, hi;
-    const f32x2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
-    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(alo), "v"(blo));   // (volatile: stays behind tree4_eval's wait states)
-    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(ahi), "v"(bhi));
-    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
-#endif
-}
 template <int CIN, int I, int S>
 struct Tree4 {
     static constexpr bool live = Tree4<CIN, I, S * 2>::live || Tree4<CIN, I + S, S * 2>::live;
     static __device__ __forceinline__ f32x4 eval(const f32x4 *acc) {
         if constexpr (!Tree4<CIN, I + S, S * 2>::live) return Tree4<CIN, I, S * 2>::eval(acc);     // x + 0 == x
         else if constexpr (!Tree4<CIN, I, S * 2>::live) return Tree4<CIN, I + S, S * 2>::eval(acc);
-        else return pk_add4(Tree4<CIN, I, S * 2>::eval(acc), Tree4<CIN, I + S, S * 2>::eval(acc));
+        else return Tree4<CIN, I, S * 2>::eval(acc) + Tree4<CIN, I + S, S * 2>::eval(acc);
     }
 };
 template <int CIN, int I>
@@ -41,15 +26,16 @@ struct Tree4<CIN, I, 128> {
     }
 };
 
-// The tree's adds are inline assembly: hipcc's hazard recognizer does not see that they read MFMA results ("XDL write VGPR -> VALU
-// read" needs up to 18 wait states on gfx950), so every evaluation starts behind a fence no instruction may be scheduled across and
-// 32 wait states.  Two instructions per tile / task.
+// The tree on accumulator quads.  Its result goes through an empty asm statement as ONE 128-bit value: without that, hipcc sees
+// that the callers consume it element by element and scalarises the whole tree into four per-component chains of v_add_f32; with
+// it the adds stay <4 x float> and are selected as v_pk_add_f32 (two independent IEEE fp32 adds per instruction, full rate on
+// gfx90a+) -- half the vector-ALU instructions of a phase in which no MFMA runs, bit-identical results, and the compiler keeps
+// its own MFMA -> VALU hazard handling (an inline-asm v_pk_add_f32 would hide the reads from it).
 template <int CIN, int CLS>
 __device__ __forceinline__ f32x4 tree4_eval(const f32x4 *acc) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 15");
-    __builtin_amdgcn_sched_barrier(0);
-    return Tree4<CIN, CLS, 4>::eval(acc);
+    f32x4 r = Tree4<CIN, CLS, 4>::eval(acc);
+    asm volatile("" : "+v"(r));
+    return r;
 }
 
 template <int CIN> struct NAcc { static constexpr int value = CIN == 4 ? 25 : 7; };
