@@ -24,11 +24,17 @@
 //     gid = (CLS - c) mod 4 the same for every slot of a diagonal;
 //   * a workgroup = 8 waves = 4 classes x 2 row halves of one (sample, 3-group block) -- or two samples side by side when the
 //     block's diagonals fit 32 rows; 24 tiles x 2 x 4 = 192 accumulator registers per wave, two waves per SIMD;
-//   * NO LDS and NO barrier in the K loop: A (packed weights, one 4..16-byte load per lane for all row tiles of a diagonal)
-//     and B (8 bytes per lane) go from L2 straight to registers, 4..6 diagonals ahead of their MFMAs; loop order = K blocks
-//     outer, the LIVE diagonals of the block inner (a diagonal's chains run exactly ceil(L/4) blocks), one straight-line body
-//     per number of live diagonals -- ~5 other instructions per diagonal step: the first version of this loop spent more
-//     time issuing address arithmetic than the matrix pipe spent on the MFMAs.
+//   * K loop (round 4): operands come through LDS by LDS-DMA.  Measured on the round-3 form, which fetched A (one 4..16-byte
+//     load per lane) and B (8 bytes per lane) straight into registers: the launch took as long with every MFMA removed as with
+//     them (116 us), 93 us without the B loads -- the CU's vector-memory ADDRESS unit was the bound: a wave instruction costs
+//     it ~18 cycles whatever its width (tools/micro/vmem_rate.hip: dword 9, dwordx2 / dwordx4 / LDS-DMA 18 cycles per CU), and a
+//     K block needed 8 waves x 22 narrow loads = 2900 of the 3072 cycles its MFMAs take (profiles/r04_dc16_ablations.txt).
+//     Now a STAGE = one K block of one class: the packed weights (6 KB, shared by the two row halves) and the 11 input
+//     diagonals (1 KB each: 4 channel planes x 64 rows, both halves) arrive as 17 full-width global_load_lds_dwordx4 -- 1224
+//     address-unit cycles per K block instead of 2900 --, issued one stage ahead into a double-buffered LDS image and spread
+//     between the MFMAs of the running stage; the MFMA waves read their operands with ds_read (b32..b128 for A, b64 for B);
+//     one barrier per stage.  Loop order = K blocks outer, the LIVE diagonals of the block inner (a diagonal's chains run
+//     exactly ceil(L/4) blocks), one straight-line body per number of live diagonals.
 // Activations: the zero-padded diagonal-major layout of cconv4v3_dc.inc ([n][c][S+12][H+4], cell (s, th) at row s+6, col th+2).
 #include "common.h"
 #include "conv_plan.h"
@@ -40,12 +46,33 @@
 #define XD_THREADS 512
 #define XD_ROW0 6                            // == D3_S0 of cconv4v3_dc.inc (lic360_dc4_layout)
 #define XD_COL0 2
-#ifndef XD_RA
-#define XD_RA 4                              // weight operand slots of the K loop (L2-resident data)
+#define XD_STAGE_A (XD_NT * 64)                // floats of packed weights per (class, K block)
+#define XD_STAGE (XD_STAGE_A + XD_ND * 256)   // + 11 input diagonals x (4 channel planes x 64 rows): 17 KB per (buffer, class)
+#define XD_NDMA 9                             // LDS-DMAs per wave and stage: 3 weight chunks + 6 diagonals (row half 1: the 6th repeats its 5th)
+#ifndef XD_PF
+#define XD_PF 3                               // operand reads run this many diagonals ahead of their MFMAs
 #endif
-#ifndef XD_RB
-#define XD_RB 4                              // activation operand slots (deeper rings were measured: no gain)
+#ifndef XD_DSTRIDE
+#define XD_DSTRIDE 2                          // one LDS-DMA of the next stage behind every XD_DSTRIDE-th MFMA, from the stage's first on
 #endif
+#ifndef XD_PRIO
+#define XD_PRIO 1                             // issue priority of the two row halves (they share a SIMD): 0 none, 1 static for half 1, 2 swapped mid-stage, 3 alternating per diagonal
+#endif
+#ifndef XD_ORDER
+#define XD_ORDER 1                            // 1: a stage walks its diagonals longest first (5, 4, 6, 3, 7, ...), 0: in index order
+#endif
+// the i-th diagonal a body with N live diagonals (dc < N) walks
+__host__ __device__ constexpr int xd_walk(int N, int i) {
+#if XD_ORDER
+    constexpr int ord[11] = {5, 4, 6, 3, 7, 2, 8, 1, 9, 0, 10};
+    int n = 0;
+    for (int j = 0; j < 11; ++j) if (ord[j] < N) { if (n == i) return ord[j]; ++n; }
+    return -1;
+#else
+    (void)N;
+    return i;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------ slot tables (compile time)
 __host__ __device__ constexpr int xd_nslots(int dc) {
@@ -98,10 +125,10 @@ static inline int conv16dc_ngb(const lic360_conv_plan *p) { return (p->ngroup + 
 static inline int conv16dc_nkb(const lic360_conv_plan *p) { return (p->ngroup + 3) / 4; }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// packed[net][gb][class][kb][diagonal dc][lane][t < ntiles(dc)] (the diagonal's block starts at float tbase(dc) * 64): lane
-// l = 16 k + i carries A[row i][k] of the MFMA of tile tbase(dc) + t in K block kb -- the tiles of a diagonal side by side, so that
-// one 4..16-byte load per lane fetches a whole K step's weights (the kernel is bound by the NUMBER of vector memory instructions:
-// the CU's address unit takes ~16 cycles per wave instruction whatever its width):
+// packed[net][gb][class][kb][diagonal dc][lane][t < ntiles(dc)] (the diagonal's block starts at float tbase(dc) * 64; a diagonal of THREE
+// tiles is stored as [lane][2] followed by [lane][1], so that every LDS read of the kernel is a naturally aligned b32 / b64 / b128):
+// lane l = 16 k + i carries A[row i][k] of the MFMA of tile tbase(dc) + t in K block kb.  One (class, K block) record = 24 tiles =
+// 6 KB, copied verbatim into LDS by six 1 KB LDS-DMAs:
 //   row i = 4 o + r, slot r of the tile = (q, kh) with kw = c + q - kh, group g = 3 gb + q, input channel 4 (4 kb + k) + gid,
 //   gid = (class - c) mod 4.  Zero where the chain has ended (tc >= L), for o >= cout, g >= G and unused slots.
 __global__ void k_conv16dc_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int G, int cout, int hidden, int n_gb, int NKB) {
@@ -112,7 +139,11 @@ __global__ void k_conv16dc_pack(const float *__restrict__ weight, float *__restr
         const int w = (int)(e - t * (XD_NT * 64));                          // position inside the (class, K block) record
         int dcp = 0;
         while (dcp + 1 < XD_ND && xd_tbase(dcp + 1) * 64 <= w) ++dcp;
-        const int nt = xd_ntiles(dcp), wl = w - xd_tbase(dcp) * 64, l = wl / nt, tile = xd_tbase(dcp) + wl % nt;
+        const int nt = xd_ntiles(dcp), wl = w - xd_tbase(dcp) * 64;
+        int l, tt;
+        if (nt == 3) { if (wl < 128) { l = wl >> 1; tt = wl & 1; } else { l = wl - 128; tt = 2; } }
+        else { l = wl / nt; tt = wl % nt; }
+        const int tile = xd_tbase(dcp) + tt;
         const int kb = (int)(t % NKB); t /= NKB;
         const int cls = (int)(t & 3); t >>= 2;
         const int gb = (int)(t % n_gb), b = (int)(t / n_gb);
@@ -150,9 +181,11 @@ struct XdArgs {
     int ngb_all, gb_hi, n_gbv, NKB, HP;
     long SKP;
     int can_pair;                              // samples n and n + 8 always belong to the same stacked net (16 | samples per net)
+    int rs;                                    // samples per XCD and ROUND of the task walk (0: one round with every sample)
 };
 
-typedef float xd_f2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float xd_f2 __attribute__((ext_vector_type(2)));
+typedef float xd_f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ f32x4 xd_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -163,7 +196,17 @@ __device__ __forceinline__ float xd_row_shift(float edge, float v) {     // lane
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
-struct XdOps { float a[4]; };
+// LDS-DMA (the idiom of cconv16_kernels.hip): lane l's 16 bytes at sbase + voff land at LDS byte lds + 16 l.  Scalar base + 32-bit
+// lane offset: no vector address arithmetic.  hipcc does not see these VMEM operations: completion is enforced by hand (XD_WAIT0
+// before the barrier that publishes a stage).  M0 is written in the statement that reads it.
+typedef const __attribute__((address_space(1))) char *xd_gptr;            // (explicitly global: a pointer that went through asm would be flat)
+__device__ __forceinline__ void xd_dma(unsigned voff, xd_gptr sbase, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+}
+#define XD_WAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ __forceinline__ unsigned xd_lds_addr(const float *p) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) const float *)p; }
+
+struct XdOps { float a[4]; xd_f2 b; };
 
 // reference tree over the leaves of group Q's class CQ: F(i, 128) = leaf i, F(i, s) = F(i, 2s) + F(i + s, 2s), result F(CQ, 4)
 template <int I, int S>
@@ -185,11 +228,11 @@ struct XdTree<I, 128> {
 
 #ifdef XD_STAMP
 // diagnostic build only: cycles per phase, summed per wave over the launch (no product code reads these)
-__device__ unsigned long long xd_stamps[256 * 8 * 8];
+__device__ unsigned long long xd_stamps[256 * 8 * 10];
 #define XD_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[i] += t_ - t0; t0 = t_; } while (0)
 LIC360_API int lic360_xd_stamps(unsigned long long *host_out, int clear) {
     if (host_out) HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(xd_stamps), sizeof(xd_stamps)));
-    if (clear) { static unsigned long long z[256 * 8 * 8]; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(xd_stamps), z, sizeof(z))); }
+    if (clear) { static unsigned long long z[256 * 8 * 10]; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(xd_stamps), z, sizeof(z))); }
     return 0;
 }
 #else
@@ -197,14 +240,17 @@ LIC360_API int lic360_xd_stamps(unsigned long long *host_out, int clear) {
 #endif
 
 template <int CLS>
-__device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *comb, const int lane, const int whalf) {
+__device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *halo, float *comb, const int lane, const int whalf) {
     const int G = a.G, H = a.H, W = a.W, S = H + W - 1, C = G * 4, nout = G * a.cout, HP = a.HP;
     const long SKP = a.SKP;
-    const int SKP4 = (int)(4 * SKP);
     const int n16 = lane & 15, kl = lane >> 4;
     // ---- task list of this workgroup: XCD-aware static walk, heaviest group blocks first, boustrophedon (cconv4v6_dc.inc)
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x - xcd + 7) >> 3;
     const int ns_x = (a.N - xcd + 7) >> 3;                                  // samples of this XCD: n = xcd + 8 m
+    // ROUNDS: the walk below (heaviest group blocks first) runs over RS samples of the XCD at a time.  Every group block of a sample
+    // reads the same band of input diagonals (block gb the channels of groups < 3 gb + 8); inside a round the bands stay in the
+    // XCD's L2 between the sweeps of the group blocks.
+    const int RS = a.rs > 0 ? a.rs : ns_x, n_rounds = a.rs > 0 ? ns_x / a.rs : 1;   // (host: 8 rs | N)
     // window of group block gb: the input rows its (up to) three diagonals read.  They fit 32 rows -> the task takes TWO samples,
     // one per row half, on the window [T0, T0 + 32) (return value = T0); otherwise one sample on rows 0..63 (return value -1).
     // (computed here from scalars: indexing a table in the kernel arguments with a run-time index makes hipcc treat the whole
@@ -223,44 +269,41 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
     unsigned span_mask = 0;                                                 // bit j: block gb_hi - j takes one sample per task
     for (int j = 0; j < a.n_gbv; ++j) span_mask |= (window_of(a.gb_hi - j) < 0 ? 1u : 0u) << j;
     span_mask = __builtin_amdgcn_readfirstlane(span_mask);
-#ifdef XD_EXP_HALFWG                                                          // experiment (timing only): 4-wave workgroups, one row half per task, no halo
-    auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? 2 * ns_x : ns_x; };
-#else
-    auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? ns_x : (ns_x + 1) >> 1; };
-#endif
-    int n_my = 0;
-    for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
+    auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? RS : (RS + 1) >> 1; };
+    int n_round = 0;                                                        // tasks of one round
+    for (int j = 0; j < a.n_gbv; ++j) n_round += units_of(j);
+    const int n_my = n_round * n_rounds;
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #ifdef XD_STAMP
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- task descriptors.  The walk is software-pipelined: task k + 1 is decoded and its first operand loads are issued BEFORE
-    // the epilogue of task k (the operand slots are free then), so no task starts by waiting for memory.
+    // ---- task descriptors.  The walk is software-pipelined: task k + 1 is decoded BEFORE the K loop of task k, whose last stage
+    // issues the LDS-DMAs of task k + 1's first stage.
     struct Task {
         int tc0, s0, n_w, net, pbase, X, nKmax, half;
+        unsigned d0, d1;                                                    // byte distance of row half 0's / 1's sample from xs
         bool span, valid_w;
-        const char *xs, *ws;
+        xd_gptr xs, ws;
     };
-    int scan_j = 0, scan_base = 0;                                          // block of the walk's current task and its first task index
+    int scan_j = 0, scan_base = 0, round = 0;                               // block of the walk's current task, its first task index, the round
     auto decode = [&](int kt, Task &t) __attribute__((always_inline)) {
         const int u = kt * wgs_per_xcd + ((kt & 1) ? wgs_per_xcd - 1 - wg_in_xcd : wg_in_xcd);
         if (u >= n_my) return false;
+        while (u >= (round + 1) * n_round) { ++round; scan_j = 0; scan_base = round * n_round; }                          // (u grows with kt)
         while (scan_j < a.n_gbv - 1 && u >= scan_base + units_of(scan_j)) { scan_base += units_of(scan_j); ++scan_j; }   // (u grows with kt)
         const int rem = u - scan_base, gb = a.gb_hi - scan_j;
         t.span = (span_mask >> scan_j) & 1u;
         t.tc0 = gb * XD_GB; t.s0 = a.psum - t.tc0;
         const int T0 = t.span ? 0 : window_of(gb);
-#ifdef XD_EXP_HALFWG
-        const int half = t.span ? (rem & 1) : 0;
-        int n_w = t.span ? xcd + 8 * (rem >> 1) : xcd + 8 * rem;
-        t.valid_w = n_w < a.N;
-#else
         const int half = whalf;
-        int n_w = t.span ? xcd + 8 * rem : xcd + 16 * rem + 8 * half;
-        t.valid_w = n_w < a.N;
-        if (!t.valid_w) n_w = xcd + 16 * rem;                               // the idle half of an odd pair recomputes sample A and stores nothing
-#endif
+        // samples of the two row halves: one sample (span) or the pair (n, n + 8); the idle half of an odd pair recomputes sample A
+        // and stores nothing
+        const int m0 = round * RS;                                          // the round's samples: n = xcd + 8 (m0 + i), i < RS
+        const bool lone = !t.span && 2 * rem + 1 >= RS;                     // the last pair of an odd round has one sample
+        const int nA = xcd + 8 * (m0 + (t.span ? rem : 2 * rem)), nB = (t.span || lone || nA + 8 >= a.N) ? nA : nA + 8;
+        int n_w = half ? nB : nA;
+        t.valid_w = t.span || half == 0 || nB != nA;
         t.half = half;
         t.n_w = n_w;
         int net = 0;                                                        // n_w / npb without a division (few stacked nets)
@@ -269,173 +312,169 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
         t.pbase = T0 + (t.span ? 32 * half : 0);
         t.X = t.tc0 + 4 + a.hidden + XD_C0;                                 // chain length of diagonal dc: min(G, X - dc)
         t.nKmax = ((t.X < G ? t.X : G) + 3) >> 2;
-#ifdef XD_EXP_SAMEX                                                           // ablation: every sample reads sample xcd's activations (L2-resident)
-        t.xs = (const char *)(a.x + (long)(xcd) * C * SKP + (long)t.s0 * HP + XD_COL0);
-#else
-        t.xs = (const char *)(a.x + (long)(n_w < a.x_mod ? n_w : n_w % a.x_mod) * C * SKP + (long)t.s0 * HP + XD_COL0);
-#endif
-        t.ws = (const char *)(a.packed + ((((long)net * a.ngb_all + gb) * 4 + CLS) * a.NKB) * (XD_NT * 64));
+        // the task's input: both halves' samples relative to the lower of the two (the lane offsets of a DMA are unsigned)
+        const int iA = nA < a.x_mod ? nA : nA % a.x_mod, iB = nB < a.x_mod ? nB : nB % a.x_mod, i0 = iA < iB ? iA : iB;
+        const long sample_bytes = (long)C * SKP * 4;
+        t.d0 = (unsigned)((iA - i0) * sample_bytes); t.d1 = (unsigned)((iB - i0) * sample_bytes);    // (< 2^32: checked by the host)
+        t.xs = (xd_gptr)(a.x + (long)i0 * C * SKP + (long)t.s0 * HP + XD_COL0);
+        t.ws = (xd_gptr)(a.packed + ((((long)net * a.ngb_all + gb) * 4 + CLS) * a.NKB) * XD_STAGE_A);
+        t.pbase = T0 + (t.span ? 32 * half : 0);
+        // rows of the two halves inside the 64-row LDS image: span: rows 0..63 of one sample; pair: the window [T0, T0 + 32) of each
+        t.tc0 = gb * XD_GB;
         return true;
     };
-    // operand addresses = scalar base + 32-bit lane offset (no vector address arithmetic in the K loop): lane (k, n) reads channel
-    // plane 4 (4 kb + k) + gid at rows pe, pe + 1 (4 | G: a K block never leaves the sample's planes)
-    unsigned offx[4], offw[4];                                              // per input channel gid / per tile count of a diagonal
-#pragma unroll
-    for (int g = 0; g < 4; ++g) offw[g] = (unsigned)lane * 4u * (unsigned)(g + 1);
-    int pe = 0;                                                             // first of this lane's two input rows
-    auto lane_rows = [&](const Task &t) __attribute__((always_inline)) {
-        pe = t.pbase + 2 * n16;
-        { const int pmax = (H + 1) & ~1; if (pe > pmax) pe = pmax; }         // rows >= H: the zero columns behind the image
-#pragma unroll
-        for (int g = 0; g < 4; ++g) offx[g] = (unsigned)((kl * 4 + g) * (int)SKP + pe) * 4u;
+    // ---- LDS-DMA lane offsets.  A: lane l copies bytes [16 l, 16 l + 16) of a 1 KB chunk.  B (one input diagonal of one K block,
+    // both row halves): lane l = 32 kk + 16 h + 8 k1 + m fetches rows r0(h) + 4 m .. + 3 of channel plane k = 2 kk + k1 of half h's
+    // sample, and its 16 bytes land in slot l -- the slot order that makes the MFMA waves' ds_read_b64 conflict-free (a 32-lane group
+    // reads the 16 slots {16 kk' + 8 k1 + m} of its half, distinct modulo 16).  Rows >= H + 2 hold whatever lies behind the row in
+    // the layout (finite activations or zeros): they only reach outputs of rows >= H, which are never stored.
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma_lane_offset = [&](const Task &t) __attribute__((always_inline)) -> unsigned {
+        const int h = (lane >> 4) & 1, k = 2 * (lane >> 5) + ((lane >> 3) & 1), m = lane & 7;
+        int r = (t.span ? 32 * h : t.pbase) + 4 * m;                         // (pair: pbase = T0 for both halves)
+        if (r >= H + 2) r = H - 2 > 0 ? H - 2 : 0;                           // stay inside the sample's planes
+        return (unsigned)((4 * k * (int)SKP + r) * 4) + (h ? t.d1 : t.d0);
     };
-    typedef const __attribute__((address_space(1))) char *gptr;               // (explicitly global: a pointer that went through asm would be flat)
-    const unsigned kbx = 16u * (unsigned)SKP4;                              // bytes between K blocks of x (< 2^32: one sample's planes)
-    const unsigned hp4 = (unsigned)HP * 4u;
+    const unsigned hp4 = (unsigned)HP * 4u, skp4 = (unsigned)SKP * 4u;
+    const unsigned kbx = 16u * skp4;                                        // bytes between K blocks of x (< 2^32: one sample's planes)
+    // the 9 LDS-DMAs of one wave for one stage (weights of K block at wk, activations at xk) into the stage image at LDS byte `dst`:
+    // j < 3: weight chunk 3 half + j;  j >= 3: diagonal dc = 6 half + j - 3 (half 1: 6..10, the last one twice -- same bytes)
+    auto dma_one = [&](auto jj, xd_gptr xk, xd_gptr wk, unsigned voff, unsigned dst) __attribute__((always_inline)) {
+        constexpr int j = decltype(jj)::value;
+        if constexpr (j < 3) {
+            const unsigned ch = (3u * (unsigned)whalf + j) * 1024u;
+            xd_dma(lane16, wk + ch, dst + ch);
+        } else {
+            int dc = 6 * whalf + (j - 3);
+            dc = dc > XD_ND - 1 ? XD_ND - 1 : dc;
+            const unsigned gid = (unsigned)(CLS + XD_C0 + 16 - dc) & 3u;    // input channel inside a group: (class - c) mod 4, c = dc - XD_C0
+            xd_dma(voff, xk + ((unsigned)dc * hp4 + gid * skp4), dst + (unsigned)(XD_STAGE_A + dc * 256) * 4u);
+        }
+    };
+    // ---- MFMA-side operand reads: lane (k, n) of half h reads its two rows (8 bytes) of plane k from slot 32 (k >> 1) + 16 h + 8 (k & 1) + (n >> 1)
+    const int boff = 4 * (32 * (kl >> 1) + 16 * whalf + 8 * (kl & 1) + (n16 >> 1)) + 2 * (n16 & 1);   // floats inside a diagonal's 1 KB chunk
     f32x4 acc[XD_NT][2];
-    // ---- K loop machinery: K blocks outer, the live diagonals of a block inner.  Diagonal dc is live in block kb while 4 kb < its
-    // chain length, i.e. the live ones are the prefix dc < D(kb) = min(11, X - 4 kb).
-        auto loadB = [&](auto dd, xd_f2 &b, gptr xk) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, gid = (CLS - (dc - XD_C0) + 16) & 3;
-            gptr xb = xk + (unsigned)dc * hp4;
-            asm volatile("" : "+s"(xb), "+v"(offx[gid]));                   // scalar base + 32-bit lane offset: global_load v, v_off, s[base]
-#ifdef XD_EXP_NOB                                                             // ablations (timing only, results are garbage)
-            if (a.N < 0)
-#endif
-            b = *(const __attribute__((address_space(1))) xd_f2 *)(xb + offx[gid]);
-        };
-        auto loadA = [&](auto dd, XdOps &o, gptr wk) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
-            typedef float xd_fT __attribute__((ext_vector_type(T == 3 ? 3 : T), aligned(T == 3 ? 4 : 4 * T)));
-            gptr wb = wk + tb * 256;
-            asm volatile("" : "+s"(wb), "+v"(offw[T - 1]));                 // (else hipcc widens the lane offset to 64 bits once and adds in the VALU)
-#ifdef XD_EXP_NOA
-            if (a.N < 0)
-#endif
-            {
-                if constexpr (T == 1) o.a[0] = *(const __attribute__((address_space(1))) float *)(wb + offw[0]);
-                else {
-                    const xd_fT v = *(const __attribute__((address_space(1))) xd_fT *)(wb + offw[T - 1]);
-#pragma unroll
-                    for (int t = 0; t < T; ++t) o.a[t] = v[t];
-                }
+    auto load_ops = [&](auto dd, XdOps &o, const float *sA) __attribute__((always_inline)) {
+        constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
+        const float *p = sA + tb * 64;
+        if constexpr (T == 1) o.a[0] = p[lane];
+        else if constexpr (T == 2) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; }
+        else if constexpr (T == 3) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; o.a[2] = p[128 + lane]; }
+        else { const f32x4 v = *(const f32x4 *)(p + 4 * lane); o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3]; }
+        o.b = *(const xd_f2 *)(sA + XD_STAGE_A + dc * 256 + boff);
+    };
+    // the MFMAs of diagonal dc; `hook(IC<m>{})` runs behind the m-th MFMA of the stage (the LDS-DMAs of the next stage go there, one
+    // per MFMA from the stage's first on: a DMA issued that early has the whole stage to land, and its ~6 scalar instructions sit
+    // in the shadow of the MFMA in front of it)
+    auto fma = [&](auto dd, auto mm0, const XdOps &o, auto &&hook) __attribute__((always_inline)) {
+        constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc), M0 = decltype(mm0)::value;   // M0: MFMAs of the stage before this diagonal
+        static_for<T>([&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, acc[tb + t][0]);
+            hook(IC<M0 + 2 * t>{});
+            acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, acc[tb + t][1]);
+            hook(IC<M0 + 2 * t + 1>{});
+        });
+    };
+    // One stage = one K block: N live diagonals (three straight-line bodies, for up to 11, 7 and 3 live diagonals; a block with D live
+    // diagonals runs in the smallest body >= D: a dead diagonal inside it multiplies zero weights -- the packed array is zero past a
+    // chain's end -- with whatever its rows hold: exact, ~5 % more MFMAs).  Operand reads run two diagonals ahead of their MFMAs; the
+    // LDS-DMAs of the NEXT stage go behind the stage's first nine MFMAs (the workgroup's very last stage fetches itself again:
+    // straight-line code, nobody reads that image); the stage ends with the wait + barrier that publishes the next stage's image and
+    // frees this one (with the DMAs spread over the whole stage, that wait was 28 % of a wave's time: the late ones had not landed).
+    unsigned stage = 0;                                                     // parity = the LDS buffer the current stage reads
+    auto stage_image = [&](unsigned par) __attribute__((always_inline)) { return ring + ((par & 1u) * 4 + CLS) * XD_STAGE; };
+    auto body = [&](auto NN, xd_gptr xk1, xd_gptr wk1, unsigned voff1) __attribute__((always_inline)) {
+        constexpr int N = decltype(NN)::value, NM = 2 * xd_tbase(N);        // MFMAs of the stage
+        const float *sA = stage_image(stage);
+        const unsigned dst = xd_lds_addr(stage_image(stage + 1));
+        auto hook = [&](auto mm) __attribute__((always_inline)) {
+            constexpr int m = decltype(mm)::value;
+            if constexpr (m % XD_DSTRIDE == 0 && m / XD_DSTRIDE < XD_NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_one(IC<m / XD_DSTRIDE>{}, xk1, wk1, voff1, dst);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto fma = [&](auto dd, const XdOps &o, const xd_f2 &b) __attribute__((always_inline)) {
-            constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-#ifdef XD_EXP_NOMFMA
-                acc[tb + t][0][0] += o.a[t] * b.x;
-#else
-                acc[tb + t][0] = xd_mfma(o.a[t], b.x, acc[tb + t][0]);
-                acc[tb + t][1] = xd_mfma(o.a[t], b.y, acc[tb + t][1]);
+        XdOps ops[XD_PF + 1];
+        static_for<(XD_PF < N ? XD_PF : N)>([&](auto ii) { load_ops(IC<xd_walk(N, decltype(ii)::value)>{}, ops[decltype(ii)::value], sA); });
+        static_for<N>([&](auto ii) {
+            constexpr int i = decltype(ii)::value, dc = xd_walk(N, i);
+            constexpr int m0 = [] { int m = 0; for (int j = 0; j < i; ++j) m += 2 * xd_ntiles(xd_walk(N, j)); return m; }();
+            if constexpr (i + XD_PF < N) load_ops(IC<xd_walk(N, i + XD_PF)>{}, ops[(i + XD_PF) % (XD_PF + 1)], sA);
+#if XD_PRIO == 3
+            if ((i + whalf) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif XD_PRIO == 2
+            if constexpr (i == 0) { if (whalf) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+            if constexpr (i == (N > 7 ? 4 : (N > 3 ? 3 : 1))) { if (whalf) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
-            }
-        };
-        // operand slots: weights of diagonal dc in sa[dc % XD_RA], activations in sb[dc % XD_RB]; after the MFMAs of (kb, dc) a slot is
-        // refilled with its next content, (kb, dc + R) or (kb + 1, dc % R): activations (may miss every cache) run further ahead
-        XdOps sa[XD_RA];
-        xd_f2 sb[XD_RB];
-        // Three straight-line block bodies, for up to 11, 7 and 3 live diagonals: every load is unconditional, so hipcc's wait counts
-        // are exact.  A block with D live diagonals runs in the smallest body >= D; a dead diagonal inside it multiplies zero weights
-        // (the packed array is zero past a chain's end) with whatever its rows hold: exact, ~5 % more MFMAs.  Since D drops by 4 per
-        // block, a task is [body 11]* [body 7]? [body 3]?  (Scalar conditions per diagonal instead: every step waited for ALL loads.
-        // A switch over eleven bodies: hipcc spilled every accumulator around every MFMA.)
-        auto body = [&](auto NN, auto NX, gptr xk, gptr xk1, gptr wk, gptr wk1) __attribute__((always_inline)) {
-            constexpr int N = decltype(NN)::value, NEXT = decltype(NX)::value;   // NEXT: diagonals the following block's body runs
-            constexpr int NA = NEXT < XD_RA ? NEXT : XD_RA, NB = NEXT < XD_RB ? NEXT : XD_RB;     // slots it expects filled
-#ifndef XD_INTERLEAVE
-            static_for<N>([&](auto dd) {
-                constexpr int dc = decltype(dd)::value, la = dc % XD_RA, lb = dc % XD_RB;
-                fma(dd, sa[la], sb[lb]);
-                if constexpr (dc + XD_RB < N) loadB(IC<dc + XD_RB>{}, sb[lb], xk); else if constexpr (lb < NB) loadB(IC<lb>{}, sb[lb], xk1);
-                if constexpr (dc + XD_RA < N) loadA(IC<dc + XD_RA>{}, sa[la], wk); else if constexpr (la < NA) loadA(IC<la>{}, sa[la], wk1);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-#else
-            // experiment (tools/xd_lone.sh): the refill of a diagonal's operand slots is issued BETWEEN the first MFMAs of the following
-            // diagonal, one load group behind each -- ~3 instructions hide in the 32-cycle shadow of an MFMA, nine in a row after the
-            // last MFMA of a diagonal do not (tools/micro/mfma_issue.hip).  No effect with two waves per SIMD (116.3-119.5 us against 116.8).
-            auto refillB = [&](auto dd) __attribute__((always_inline)) {
-                constexpr int d = decltype(dd)::value, lb = d % XD_RB;
-                if constexpr (d + XD_RB < N) loadB(IC<d + XD_RB>{}, sb[lb], xk); else if constexpr (lb < NB) loadB(IC<lb>{}, sb[lb], xk1);
-            };
-            auto refillA = [&](auto dd) __attribute__((always_inline)) {
-                constexpr int d = decltype(dd)::value, la = d % XD_RA;
-                if constexpr (d + XD_RA < N) loadA(IC<d + XD_RA>{}, sa[la], wk); else if constexpr (la < NA) loadA(IC<la>{}, sa[la], wk1);
-            };
-            static_for<N>([&](auto dd) {
-                constexpr int dc = decltype(dd)::value, la = dc % XD_RA, lb = dc % XD_RB, T = xd_ntiles(dc), tb = xd_tbase(dc);
-                acc[tb][0] = xd_mfma(sa[la].a[0], sb[lb].x, acc[tb][0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (dc >= 1) refillB(IC<(dc >= 1 ? dc - 1 : 0)>{});
-                __builtin_amdgcn_sched_barrier(0);
-                acc[tb][1] = xd_mfma(sa[la].a[0], sb[lb].y, acc[tb][1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (dc >= 1) refillA(IC<(dc >= 1 ? dc - 1 : 0)>{});
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 1; t < T; ++t) {
-                    acc[tb + t][0] = xd_mfma(sa[la].a[t], sb[lb].x, acc[tb + t][0]);
-                    acc[tb + t][1] = xd_mfma(sa[la].a[t], sb[lb].y, acc[tb + t][1]);
-                }
-                if constexpr (dc == N - 1) { __builtin_amdgcn_sched_barrier(0); refillB(IC<N - 1>{}); refillA(IC<N - 1>{}); }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-#endif
-        };
-        auto fill = [&](const Task &t) __attribute__((always_inline)) {       // operands of block 0, the first diagonals (rows always exist)
-            static_for<XD_RB>([&](auto ss) { loadB(ss, sb[decltype(ss)::value], (gptr)t.xs); });
-            static_for<XD_RA>([&](auto ss) { loadA(ss, sa[decltype(ss)::value], (gptr)t.ws); });
-        };
+            __builtin_amdgcn_sched_barrier(0);
+            fma(IC<dc>{}, IC<m0>{}, ops[i % (XD_PF + 1)], hook);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<((NM + XD_DSTRIDE - 1) / XD_DSTRIDE < XD_NDMA ? XD_NDMA - (NM + XD_DSTRIDE - 1) / XD_DSTRIDE : 0)>([&](auto rr) {
+            dma_one(IC<(NM + XD_DSTRIDE - 1) / XD_DSTRIDE + decltype(rr)::value>{}, xk1, wk1, voff1, dst);
+        });
+        XD_T(1);
+        XD_WAIT0();
+        XD_T(7);                                                            // (diagnostic build: the wait for this wave's own DMAs ...
+        __syncthreads();
+        XD_T(8);                                                            //  ... and the stage barrier)
+        ++stage;
+    };
     Task cur, nxt;
     if (!decode(0, cur)) return;                                            // (uniform over the workgroup)
-    lane_rows(cur);
-    fill(cur);
+    unsigned voff = dma_lane_offset(cur);
+    {   // the first stage of the first task
+        const unsigned dst = xd_lds_addr(stage_image(0));
+        static_for<XD_NDMA>([&](auto jj) { dma_one(jj, cur.xs, cur.ws, voff, dst); });
+        XD_WAIT0();
+        __syncthreads();
+    }
     for (int kt = 0;; ++kt) {
         const int tc0 = cur.tc0, s0 = cur.s0, n_w = cur.n_w, net = cur.net, pbase = cur.pbase;
-#ifdef XD_EXP_HALFWG
-        const bool span = false, valid_w = cur.valid_w;
-        const int half = 0;
-#else
         const bool span = cur.span, valid_w = cur.valid_w;
         const int half = cur.half;
-#endif
+        const bool have_next = decode(kt + 1, nxt);
+        const unsigned voff_n = have_next ? dma_lane_offset(nxt) : voff;
 #pragma unroll
         for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
         XD_T(0);
         {
-            gptr xk = (gptr)cur.xs, wk = (gptr)cur.ws;
+            xd_gptr xk = cur.xs, wk = cur.ws;
             const int X = cur.X;
             int nKmax = cur.nKmax;
             asm volatile("" : "+s"(nKmax));
             int kb = 0, D = X;                                                  // live diagonals of block kb (uncapped)
-            auto next_ptrs = [&](gptr &xk1, gptr &wk1) __attribute__((always_inline)) {
-                const bool more = kb + 1 < nKmax;                               // the task's last block re-reads itself
-                xk1 = xk + (more ? kbx : 0u); wk1 = wk + (more ? (unsigned)(XD_NT * 256) : 0u);
+            // operands of the stage after block kb: block kb + 1 of this task, or block 0 of the next one (none: this block again)
+            auto next_stage = [&](xd_gptr &xk1, xd_gptr &wk1, unsigned &v1) __attribute__((always_inline)) {
+                const bool inner = kb + 1 < nKmax;
+                xk1 = inner ? xk + kbx : (have_next ? nxt.xs : xk);
+                wk1 = inner ? wk + (unsigned)(XD_STAGE_A * 4) : (have_next ? nxt.ws : wk);
+                v1 = inner ? voff : voff_n;
                 asm volatile("" : "+s"(xk1), "+s"(wk1));
             };
             for (; kb < nKmax && D >= 8; ++kb, D -= 4) {
-                gptr xk1, wk1;
-                next_ptrs(xk1, wk1);
-                body(IC<XD_ND>{}, IC<XD_ND>{}, xk, xk1, wk, wk1);                // next: body 11 or 7 (a dead diagonal's operands: harmless)
+                xd_gptr xk1, wk1; unsigned v1;
+                next_stage(xk1, wk1, v1);
+                body(IC<XD_ND>{}, xk1, wk1, v1);
                 xk = xk1; wk = wk1;
             }
             if (kb < nKmax && D >= 4) {
-                gptr xk1, wk1;
-                next_ptrs(xk1, wk1);
-                body(IC<7>{}, IC<3>{}, xk, xk1, wk, wk1);
+                xd_gptr xk1, wk1; unsigned v1;
+                next_stage(xk1, wk1, v1);
+                body(IC<7>{}, xk1, wk1, v1);
                 xk = xk1; wk = wk1; ++kb; D -= 4;
             }
-            if (kb < nKmax) body(IC<3>{}, IC<0>{}, xk, xk, wk, wk);
+            if (kb < nKmax) {
+                xd_gptr xk1, wk1; unsigned v1;
+                next_stage(xk1, wk1, v1);
+                body(IC<3>{}, xk1, wk1, v1);
+            }
         }
         XD_T(1);
-        // ---- the next task: decode, lane offsets, first operand loads (in flight during this task's epilogue)
-        const int pe_e = pe;                                                // this task's rows, for the epilogue
-        const bool have_next = decode(kt + 1, nxt);
-        if (have_next) { lane_rows(nxt); fill(nxt); }
         // ---- epilogue operands of the waves that finish a group (class q < 3 finishes group q of its half): fetched after the K loop (they would cost 7 registers inside it), used after two barriers
+        const int pe_e = pbase + 2 * n16;                                   // first of this lane's two rows
         float e_bias = 0.f, e_act = 0.f;
         xd_f2 e_res = {0.f, 0.f};
         long e_oi = 0;
@@ -444,20 +483,17 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
             const int q = CLS, g = tc0 + q, sq = s0 - q, o = kl;
             const bool vq = valid_w && g < G && sq >= 0 && sq < S && o < a.cout;
             const int lo = sq >= W ? sq - W + 1 : 0, hi = sq < H ? sq : H - 1;
-            const int p0 = pbase + 2 * n16;
+            const int p0 = pe_e;
             e_ok0 = vq && p0 >= lo && p0 <= hi;
             e_ok1 = vq && p0 + 1 >= lo && p0 + 1 <= hi;
             const int gc = g < G ? g : G - 1, oc = o < a.cout ? o : a.cout - 1, sc = sq < 0 ? 0 : (sq >= S ? S - 1 : sq);
             const int bid = net * nout + gc * a.cout + oc;
-            e_oi = ((long)n_w * nout + gc * a.cout + oc) * SKP + (long)(sc + XD_ROW0) * HP + pe_e + XD_COL0;
+            const int pc = pe_e > ((H + 1) & ~1) ? ((H + 1) & ~1) : pe_e;    // (rows behind the image: any address inside the row)
+            e_oi = ((long)n_w * nout + gc * a.cout + oc) * SKP + (long)(sc + XD_ROW0) * HP + pc + XD_COL0;
             e_bias = a.bias[bid];
             e_act = act_p[bid];
-            e_res = *(const xd_f2 *)(res_p + (a.residual ? e_oi : 0));
+            e_res = *(const xd_f2u *)(res_p + (a.residual ? e_oi : 0));
         }
-#ifdef XD_EXP_NOEPI
-        if (a.N < 0)
-#endif
-        {
         // ---- halo: the partner half's edge column of every shifted slot (only when the two halves are one sample)
         if (span) {
             if (half == 1) {
@@ -545,55 +581,43 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *halo, float *com
                 if (a.residual) v = v + (t == 0 ? e_res.x : e_res.y);        // fused TileAdd
                 sv[t] = v;
             }
-            if (e_ok0 && e_ok1) *(xd_f2 *)(a.out + e_oi) = (xd_f2){sv[0], sv[1]};
+            if (e_ok0 && e_ok1) *(xd_f2u *)(a.out + e_oi) = (xd_f2u){sv[0], sv[1]};
             else if (e_ok0) a.out[e_oi] = sv[0];
             else if (e_ok1) a.out[e_oi + 1] = sv[1];
-        }
         }
         XD_T(6);
         if (!have_next) break;
         cur = nxt;
-#ifdef XD_EXP_NOEPI
-        if (acc[0][0][0] == 1.2345f && acc[23][1][3] == 5.f) a.out[0] = acc[5][0][1] + acc[11][1][2] + acc[17][0][0];   // keep the K loops alive
-#endif
+        voff = voff_n;
     }
 #ifdef XD_STAMP
     if (lane == 0) {
-        st[7] += __builtin_amdgcn_s_memtime() - t0;
-        for (int i = 0; i < 8; ++i) xd_stamps[((blockIdx.x & 255) * 8 + whalf * 4 + CLS) * 8 + i] += st[i];
+        for (int i = 0; i < 10; ++i) xd_stamps[((blockIdx.x & 255) * 8 + whalf * 4 + CLS) * 10 + i] += st[i];
     }
 #endif
 }
 
-#ifdef XD_EXP_HALFWG
-#undef XD_THREADS
-#define XD_THREADS 256
-#endif
 __global__ __launch_bounds__(XD_THREADS, 2) void k_cconv16dc(XdArgs a) {
+    __shared__ __attribute__((aligned(16))) float ring[2 * 4 * XD_STAGE];   // [buffer][class][weights 6 KB | 11 diagonals x 1 KB]: 136 KB
     __shared__ float halo[(2 * 4 + 1) * XD_NHALO * 4];                      // [direction][class][register][channel] + a block of zeros
+    __shared__ float comb[XD_GB * 2 * 4 * 2 * 64];
     for (int i = threadIdx.x; i < XD_NHALO * 4; i += XD_THREADS) halo[2 * 4 * XD_NHALO * 4 + i] = 0.f;
     __syncthreads();
-    __shared__ float comb[XD_GB * 2 * 4 * 2 * 64];
-#ifdef XD_EXP_LONE                                                            // experiment: one workgroup per CU (LDS ballast)
-    __shared__ float ballast[24 * 1024];
-    if (a.N < 0) { ballast[threadIdx.x] = 1.f; __syncthreads(); comb[threadIdx.x] = ballast[threadIdx.x ^ 1]; }
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cls = wave & 3, half = wave >> 2;
-#ifdef XD_EXP_EMPTY
-    if (a.N > 0) return;
+#if XD_PRIO == 1
+    // The two row halves of a class share a SIMD and every stage ends in a barrier: with equal priorities the older wave (half 0) wins
+    // the issue arbitration, runs its 48 MFMAs in 2400 cycles and then waits 1700 at the barrier while the younger one finishes alone
+    // at a lone wave's pace (stamps: K loops 153 k / 233 k cycles per launch, barrier waits 110 k / 9 k).  Static priority for the
+    // younger half (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
+    if (half) __builtin_amdgcn_s_setprio(1);
 #endif
-#ifdef XD_ONE_CLASS
-    (void)cls;
-    xd_body<1>(a, halo, comb, lane, half);
-#else
     switch (cls) {
-        case 0: xd_body<0>(a, halo, comb, lane, half); break;
-        case 1: xd_body<1>(a, halo, comb, lane, half); break;
-        case 2: xd_body<2>(a, halo, comb, lane, half); break;
-        default: xd_body<3>(a, halo, comb, lane, half); break;
+        case 0: xd_body<0>(a, ring, halo, comb, lane, half); break;
+        case 1: xd_body<1>(a, ring, halo, comb, lane, half); break;
+        case 2: xd_body<2>(a, ring, halo, comb, lane, half); break;
+        default: xd_body<3>(a, ring, halo, comb, lane, half); break;
     }
-#endif
 }
 
 // x / residual / out: the zero-padded diagonal-major layout of lic360_dc4_layout (row0 = 6, col0 = 2); h <= 64.
@@ -605,11 +629,16 @@ LIC360_API int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *p, 
     int rows, pitch, row0, col0;
     if (lic360_dc4_layout(h, w, &rows, &pitch, &row0, &col0)) return 2;
     ARG_CHECK(row0 == XD_ROW0 && col0 == XD_COL0);
+    ARG_CHECK(8L * G * 4 * rows * pitch * 4 < (1L << 32));                  // a pair's samples (n, n + 8) inside one 32-bit lane offset
     XdArgs a;
     a.x = x; a.packed = packed; a.bias = bias; a.act = act; a.residual = residual; a.out = out;
     a.G = G; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w; a.npb = n / nb; a.x_mod = x_mod; a.N = n; a.psum = psum;
     a.ngb_all = conv16dc_ngb(p); a.NKB = conv16dc_nkb(p); a.HP = pitch; a.SKP = (long)rows * pitch;
-    a.can_pair = (a.npb % 16) == 0 ? 1 : 0;                                // samples n, n + 8 of an XCD's list then share a net
+    a.can_pair = (a.npb % 16) == 0 && x_mod == n ? 1 : 0;                  // samples n, n + 8 of an XCD's list then share a net (and x is not shared)
+    // rounds of the task walk: LIC360_DC_RS=<k>: k samples per XCD and round (default 0: one round)
+    static const int rs_env = [] { const char *e = getenv("LIC360_DC_RS"); return e ? atoi(e) : 0; }();
+    a.rs = 0;
+    if (rs_env > 0 && n % 8 == 0 && (n / 8) % rs_env == 0 && (rs_env % 2 == 0 || !a.can_pair)) a.rs = rs_env;
     int gb_lo = 1 << 30, gb_hi = -1;
     for (int gb = 0; gb < a.ngb_all; ++gb) {
         bool live = false;
@@ -624,11 +653,7 @@ LIC360_API int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *p, 
     if (gb_hi < 0) return 0;
     a.gb_hi = gb_hi; a.n_gbv = gb_hi - gb_lo + 1;
     ARG_CHECK(a.n_gbv <= 32);
-#ifdef XD_EXP_HALFWG
-    hipLaunchKernelGGL(k_cconv16dc, dim3(512), dim3(XD_THREADS), 0, (hipStream_t)stream, a);
-#else
     hipLaunchKernelGGL(k_cconv16dc, dim3(256), dim3(XD_THREADS), 0, (hipStream_t)stream, a);
-#endif
     LAUNCH_CHECK();
     return 0;
 }

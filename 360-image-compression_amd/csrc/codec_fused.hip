@@ -815,15 +815,6 @@ LIC360_API int lic360_codec_decode(void *stream, lic360_codec *c, const uint8_t 
                                    const float *mask, int B, float *code_out, int *err) {
     return codec_decode_impl(stream, c, bytes, cap, nbytes, mask, B, code_out, err, nullptr, 0, 1);
 }
-// The same decode behind an importance-map decode that runs on another stream and fills `mask` plane by plane
-// (lic360_impcodec_decode_masked): the convolutions of a latent plane need no mask at all, its table kernel waits for event
-// min(n_events - 1, plane / stride) before it reads the mask.  Results are those of lic360_codec_decode on the finished mask.
-LIC360_API int lic360_codec_decode_gated(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
-                                         const float *mask, int B, float *code_out, int *err, void *const *events, int n_events, int stride) {
-    ARG_CHECK(events && n_events > 0 && stride > 0);
-    return codec_decode_impl(stream, c, bytes, cap, nbytes, mask, B, code_out, err, events, n_events, stride);
-}
-
 // ------------------------------------------------------------------------------------------------ importance-map stream
 // Device-resident counterpart of ImpEntEncoderFast / ImpEntDecoder (test/lic360_demo.py:143-189, 241-290): one group, a
 // 12-layer spatially causal net with `cpg` hidden channels, an nsym-way softmax table per position
@@ -850,8 +841,15 @@ struct lic360_impcodec {
     int *d_tab;                                 // [maxB][tab_pitch][IMP_TW] tables of the current plane
     int tab_pitch;
     AcDevState *d_state;
-    // lic360_impcodec_decode_masked: one event per plane ("the latent mask of every map cell of planes <= p is final")
+    // lic360_impcodec_decode_masked: one event per plane ("the latent mask of every map cell of planes <= p is final").  The events are
+    // re-recorded by every masked decode and hipStreamWaitEvent latches whichever record came last, so a gated latent decode is only
+    // valid when it is enqueued AFTER the masked decode of the same step: decode_masked bumps gate_gen and arms the gate, decode_gated
+    // must present that generation and consumes it (a stale, reused or out-of-order gate is an error, not a silent wrong mask).
     std::vector<hipEvent_t> plane_ev;
+    long gate_gen = 0;
+    bool gate_armed = false;
+    int gate_stride = 0;
+    const float *gate_mask = nullptr;
 };
 #define IMP_TW 64                              // ints per table row (nsym + 1 <= 64), one per lane
 
@@ -1177,19 +1175,47 @@ LIC360_API int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const ui
 // (ImpEntDecoder.forward's last three lines, test/lic360_demo.py:283-287) that plane p decides are written and event p is recorded, so
 // that a latent decode on ANOTHER stream can run behind the map's decode instead of after it (lic360_codec_decode_gated): the latent
 // plane q only reads the mask of map cells (h >> 1, w >> 1) with h + w <= q, i.e. of map planes <= q / stride.
-// mask_out: [B][mask_c / stride^2][stride h][stride w]; events_out receives the codec-owned array of the P = h + w - 1 events.
+// mask_out: [B][mask_c / stride^2][stride h][stride w]; *generation_out identifies this masked decode to lic360_codec_decode_gated.
+// Caller's contract (the events are re-recorded by every call): enqueue this BEFORE the gated latent decode of the same step, and order
+// the NEXT step's masked decode into the same mask_out after the latent decode that still reads it (an event, or two mask buffers).
 LIC360_API int lic360_impcodec_decode_masked(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
-                                             float *levels_out, int *err, float *mask_out, int mask_c, int stride, void ***events_out, int *n_events) {
-    ARG_CHECK(c && mask_out && events_out && n_events && mask_c > 0 && stride > 0 && mask_c % (stride * stride) == 0 && c->nsym > 1 &&
+                                             float *levels_out, int *err, float *mask_out, int mask_c, int stride, long *generation_out) {
+    ARG_CHECK(c && mask_out && generation_out && mask_c > 0 && stride > 0 && mask_c % (stride * stride) == 0 && c->nsym > 1 &&
               mask_c % (c->nsym - 1) == 0 && B > 0 && B <= c->maxB);
     while ((int)c->plane_ev.size() < c->P) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));   // (same-device consumers only: no system-scope cache writeback per plane)
         c->plane_ev.push_back(e);
     }
-    *events_out = (void **)c->plane_ev.data();
-    *n_events = c->P;
-    return impcodec_decode_impl(stream, c, bytes, cap, nbytes, B, levels_out, err, mask_out, mask_c, stride);
+    const int rc = impcodec_decode_impl(stream, c, bytes, cap, nbytes, B, levels_out, err, mask_out, mask_c, stride);
+    c->gate_armed = rc == 0;                                            // (a failed enqueue arms nothing)
+    if (rc) return rc;
+    c->gate_stride = stride;
+    c->gate_mask = mask_out;
+    *generation_out = ++c->gate_gen;
+    return 0;
+}
+
+// The latent decode behind an importance-map decode that runs on another stream and fills `mask` plane by plane
+// (lic360_impcodec_decode_masked on `map_codec`): the convolutions of a latent plane need no mask at all, its table kernel waits for
+// the map's event min(P - 1, plane / stride) before it reads the mask.  Results are those of lic360_codec_decode on the finished mask.
+// `generation` is what that masked decode returned: it must be the map codec's LATEST masked decode, not yet consumed, into this `mask`.
+LIC360_API int lic360_codec_decode_gated(void *stream, lic360_codec *c, const uint8_t *bytes, long cap, const int *nbytes,
+                                         const float *mask, int B, float *code_out, int *err, lic360_impcodec *map_codec, long generation) {
+    ARG_CHECK(map_codec && generation > 0);
+    if (!map_codec->gate_armed || map_codec->gate_gen != generation) {
+        lic360_set_error("lic360_codec_decode_gated: stale gate (generation %ld, the map codec is at %ld, %s): enqueue "
+                         "lic360_impcodec_decode_masked of THIS step first, and use each gate once",
+                         generation, map_codec->gate_gen, map_codec->gate_armed ? "armed" : "already consumed");
+        return 2;
+    }
+    if (map_codec->gate_mask != mask) {
+        lic360_set_error("lic360_codec_decode_gated: `mask` is not the buffer the masked decode of generation %ld fills", generation);
+        return 2;
+    }
+    map_codec->gate_armed = false;
+    return codec_decode_impl(stream, c, bytes, cap, nbytes, mask, B, code_out, err, (void *const *)map_codec->plane_ev.data(), map_codec->P,
+                             map_codec->gate_stride);
 }
 
 // ------------------------------------------------------------------------------------------------ device-coder test hooks

@@ -78,8 +78,10 @@ class FusedCodec(object):
         return b
 
     def decode_async(self, mask, b=None, bytes_dev=None, nbytes_dev=None, gate=None):
-        """gate: what FusedImpCodec.decode_masked_async returned -- `mask` is then being filled plane by plane on another stream
-        and every plane's table kernel waits for the event that covers it."""
+        """gate: what FusedImpCodec.decode_masked_async returned IN THIS STEP -- `mask` (the very buffer handed to it) is then being
+        filled plane by plane on another stream and every plane's table kernel waits for the event that covers it.  A gate is a
+        one-time ticket: the map's masked decode must be enqueued first, and a gate of an earlier step (or one used twice) raises
+        instead of decoding against a stale mask.  The caller orders the NEXT masked decode into the same buffer after this decode."""
         self._check(mask, "mask")
         b = mask.shape[0] if b is None else b
         bd = self.bytes if bytes_dev is None else bytes_dev
@@ -88,9 +90,9 @@ class FusedCodec(object):
             _chk(_lib.lic360_codec_decode(_stream(self.device), self._h, _p(bd), C.c_long(bd.shape[1]), _p(nd), _p(mask), b,
                                           _p(self.code_out), _p(self.err)))
         else:
-            ev, n, stride = gate
+            map_codec, generation = gate                                  # (the tuple keeps the map codec, hence its events, alive)
             _chk(_lib.lic360_codec_decode_gated(_stream(self.device), self._h, _p(bd), C.c_long(bd.shape[1]), _p(nd), _p(mask), b,
-                                                _p(self.code_out), _p(self.err), ev, int(n), int(stride)))
+                                                _p(self.code_out), _p(self.err), map_codec._h, C.c_long(generation)))
         return self.code_out[:b]
 
     def encode(self, code, mask):
@@ -194,17 +196,17 @@ class FusedImpCodec(object):
 
     def decode_masked_async(self, b, mask_out, mask_channels=192, stride=2):
         """decode_async + the latent codec's mask Dtow(stride)(Imp2mask(levels)) into `mask_out`
-        [b, mask_channels / stride^2, stride h, stride w], refreshed after every plane.  Returns the gate
-        (events, n_events, stride) to hand to FusedCodec.decode_async(..., gate=...) ON ANOTHER STREAM: the latent decode then
-        runs behind this one instead of after it (include/lic360_hip.h: lic360_impcodec_decode_masked)."""
+        [b, mask_channels / stride^2, stride h, stride w], refreshed after every plane.  Returns the gate (this codec, ticket)
+        to hand to FusedCodec.decode_async(mask_out, ..., gate=...) ON ANOTHER STREAM, AFTER this call: the latent decode then
+        runs behind this one instead of after it (include/lic360_hip.h: lic360_impcodec_decode_masked, ordering contract)."""
         want = (int(b), mask_channels // (stride * stride), stride * self.H, stride * self.W)
         if not (mask_out.is_cuda and mask_out.dtype == torch.float32 and mask_out.is_contiguous() and tuple(mask_out.shape) == want):
             raise Lic360Error("mask_out must be a contiguous float32 device tensor %s" % (want,))
-        ev, n = C.c_void_p(0), C.c_int(0)
+        gen = C.c_long(0)
         _chk(_lib.lic360_impcodec_decode_masked(_stream(self.device), self._h, _p(self.bytes), C.c_long(self.cap), _p(self.nbytes), int(b),
                                                 _p(self.levels_out), _p(self.err), _p(mask_out), int(mask_channels), int(stride),
-                                                C.byref(ev), C.byref(n)))
-        return (ev, n.value, int(stride))
+                                                C.byref(gen)))
+        return (self, gen.value)
 
     def encode(self, levels):
         b = self.encode_async(levels)

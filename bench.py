@@ -105,6 +105,7 @@ def cpu_baseline(layers, imp_layers, code, mask, levels, gpu_bytes, gpu_imp_byte
     import numpy as np
     import ref_codec as rc
     cores = int(os.environ["OMP_NUM_THREADS"])
+    nproc, cpu_model = host_cpu()
     t0 = time.time()
     data = rc.encode_main(code, mask, layers, G)
     imp = rc.encode_imp(levels, imp_layers)
@@ -131,12 +132,43 @@ def cpu_baseline(layers, imp_layers, code, mask, levels, gpu_bytes, gpu_imp_byte
     d.close()
     c2 = time.time()
     assert np.array_equal(back.astype(np.int32), sym)
-    return {"value": PIXELS / (t2 - t0) / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+    return {"value": PIXELS / (t2 - t0) / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port", "nproc": nproc, "cpu_model": cpu_model,
             "coder_single_thread": {"symbols": int(sym.size), "bytes": len(blob), "encode_Msym_per_s": sym.size / (c1 - c0) / 1e6,
                                     "decode_Msym_per_s": sym.size / (c2 - c1) / 1e6, "note": "configs[0]: range coder only, fixed CDF, one host thread"},
             "encode_s": t1 - t0, "decode_s": t2 - t1, "gpu_bytes_equal_oracle_bytes": same,
             "sample": "oracle encode + decode of ONE whole 512x1024 image of the timed batch (image 0: latent 48x64x128 + 32x64 importance "
                       "map, full 12-layer x3 model), %.1f s on %d threads" % (t2 - t0, cores)}
+
+
+def host_cpu():
+    """(host cores this process may run on, CPU model string) -- SURVEY.md 8d asks for both beside the CPU figure"""
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc = os.cpu_count() or 1
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return nproc, model
+
+
+def newest_pmc_traffic():
+    """(dict, file name) of the newest committed PMC collection profiles/rNN_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, tools/collect_profiles.sh), newest round first"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f), os.path.basename(path)
+        except Exception:                                          # noqa: BLE001
+            continue
+    return {}, None
 
 
 def dry_run(args):
@@ -160,7 +192,7 @@ def dry_run(args):
 
 
 def run_rank(args):
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))     # the oracle's pool (cpu_baseline leg only)
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cpu()[0]))     # the oracle's pool (cpu_baseline leg only): every host core of this process
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -359,17 +391,31 @@ def run_rank(args):
             "value": world * B * args.steps * PIXELS / dt / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 512x1024 ERPs per GPU: quantised latent (48x64x128 symbols under its importance mask) AND "
-                                   "32x64 importance map of every image, model-idx 3 --ssim seeded weights, entropy encode + decode of both "
-                                   "bitstreams (BASELINE.json configs[3], per-GPU form)" % B,
+            "config": {"workload": "%d/GPU synthetic 512x1024 ERPs, model-idx 3 --ssim seed, latent+importance bitstreams, entropy enc+dec" % B,
                        "images_per_gpu_per_step": B, "streams": ns, "roundtrip_exact": ok,
                        "bit_exact_against": "CPU oracle (arithmetic coder pinned to the reference's ArithmeticCoder.cpp; float kernels unpinnable without CUDA)",
                        "mean_latent_bytes": float(nbytes.mean()), "mean_importance_bytes": float(inbytes.mean())},
         }
+        assert len(out["config"]["workload"]) <= 120
+        # the side figures as SCALAR keys of `config` (the driver's record keeps scalars only); the nested forms stay beside them
+        flat = out["config"]
+        if "latent_stream_only" in extras:
+            flat["latent_only_mpixel_s"] = extras["latent_stream_only"]["value"]
+        if "config4" in extras:
+            flat["config4_mpixel_s"], flat["config4_ms"] = extras["config4"]["value"], extras["config4"]["ms"]
+        if "config4_per_gpu_share" in extras:
+            sh = extras["config4_per_gpu_share"]
+            flat["config4_share8_ms"] = sh["ms"]
+            flat["config4_pred_8gpu_mpixel_s"] = sh["predicted_8gpu_strong"]["value"]
+            flat["config4_pred_8gpu_x"] = sh["predicted_8gpu_strong"]["vs_this_gpu_on_all_64"]
+        if "value" in extras.get("config5", {}):
+            flat["config5_mpixel_s"], flat["config5_ms"] = extras["config5"]["value"], extras["config5"]["ms"]
         out["config"].update(extras)
         out.update(instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B))
         if world == 1 and not args.no_extras:
-            out["config"]["single_image"] = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], istreams[0], mbufs[0][0], dev)
+            si = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], istreams[0], mbufs[0][0], dev)
+            out["config"]["single_image"] = si
+            out["config"]["single_encode_ms"], out["config"]["single_decode_ms"] = si["encode_ms"], si["decode_ms"]
             try:
                 import stream_ops_bench
                 rows = stream_ops_bench.measure(batches=(32,), device=local)
@@ -489,13 +535,7 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
     dom = max(convs, key=lambda r: r["total_ms"])
     # fabric-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh;
     # Infinity-Cache hits are counted), scaled to this run's images per launch
-    pmc = {}
-    for tag in ("r03", "r02"):                                        # the newest committed collection
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))
-            break
-        except Exception:                                          # noqa: BLE001
-            pass
+    pmc, pmc_file = newest_pmc_traffic()
     for r in rows:
         pm = pmc.get(r["kernel"])
         if isinstance(pm, dict):
@@ -511,7 +551,10 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
     traffic = dom.get("traffic")
     conv_ms = sum(r["total_ms"] for r in convs)
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["frac"], "traffic": traffic, "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
+                "frac": dom["frac"], "traffic": traffic,
+                "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes of tools/collect_profiles.sh, not collected in this run), scaled to "
+                                   "%d images per launch" % (pmc_file, b0)) if traffic is not None else None,
+                "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
                 "images_per_launch": b0, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
                 "how": "one sub-batch alone on the GPU, one stream, HIP events around every launch on the launch stream (instrumented pass, "
                        "outside the timed region)",

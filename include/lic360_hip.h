@@ -269,13 +269,6 @@ int lic360_codec_encode(void *stream, lic360_codec *codec, const float *code, co
 /* bitstreams + mask -> code_out [b,ngroup,h,w] (decoded symbol where mask, 0 elsewhere: `b[0:1] + 3.5*mask`, lic360_demo.py:236-237) */
 int lic360_codec_decode(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
                         const float *mask, int b, float *code_out, int *err);
-/* lic360_codec_decode behind a map decode that fills `mask` on another stream (lic360_impcodec_decode_masked): the convolutions of
- * a latent plane read no mask; the plane's table kernel waits for events[min(n_events - 1, plane / stride)].  Same results as
- * lic360_codec_decode on the finished mask.  No reference counterpart: DcEntDecoder.forward takes the finished mask
- * (test/lic360_demo.py:218-238); this only moves the 18 ms of a map's decode under the 97 ms of the latent's. */
-int lic360_codec_decode_gated(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
-                              const float *mask, int b, float *code_out, int *err, void *const *events, int n_events, int stride);
-
 /* Device-resident importance-map stream (ImpEntEncoderFast / ImpEntDecoder, test/lic360_demo.py:143-189, 241-290): one
  * group, 12 spatially causal layers with `hidden_channels` channels, nsym-way softmax tables (entropy_table_cuda.cu:24-96),
  * symbols = importance levels.  levels / levels_out: float [B,1,h,w]; weights per layer as [nout][C][5][5] (one net).
@@ -289,9 +282,20 @@ int lic360_impcodec_decode(void *stream, lic360_impcodec *c, const uint8_t *byte
 /* The map's decode AND the latent codec's mask, plane by plane: after plane p, mask_out = Dtow(stride)(Imp2mask(levels_out)) -- the
  * last three lines of ImpEntDecoder.forward (test/lic360_demo.py:283-287) -- is refreshed and the codec-owned event p is recorded,
  * so that lic360_codec_decode_gated on ANOTHER stream runs behind the map's decode instead of after it.  mask_out:
- * [B][mask_c / stride^2][stride h][stride w] (LIC360: mask_c = 192, stride = 2); *events_out / *n_events: the h + w - 1 events. */
+ * [B][mask_c / stride^2][stride h][stride w] (LIC360: mask_c = 192, stride = 2); *generation_out: the ticket of this masked decode.
+ * ORDERING CONTRACT: (1) the events are re-recorded by every call, so the gated latent decode of a step must be enqueued AFTER this call
+ * of the same step (enforced: the ticket); (2) the next step's masked decode overwrites mask_out -- order it after the latent decode
+ * that still reads the buffer (an event on the latent stream, or alternate between two mask buffers as bench.py does). */
 int lic360_impcodec_decode_masked(void *stream, lic360_impcodec *c, const uint8_t *bytes, long cap, const int *nbytes, int B,
-                                  float *levels_out, int *err, float *mask_out, int mask_c, int stride, void ***events_out, int *n_events);
+                                  float *levels_out, int *err, float *mask_out, int mask_c, int stride, long *generation_out);
+/* lic360_codec_decode behind that map decode: the convolutions of a latent plane read no mask; the plane's table kernel waits for the
+ * map codec's event min(P - 1, plane / stride).  Same results as lic360_codec_decode on the finished mask.  `generation` must be the
+ * ticket of map_codec's LATEST lic360_impcodec_decode_masked into this very `mask`, not yet used: anything else (a gate of an earlier
+ * step, a gate used twice, the latent decode enqueued first) returns an error instead of decoding against a stale mask.  map_codec
+ * must outlive the call.  No reference counterpart: EntDecoder.forward takes the finished mask (test/lic360_demo.py:218-238); this
+ * only moves the 18 ms of a map's decode under the 97 ms of the latent's. */
+int lic360_codec_decode_gated(void *stream, lic360_codec *codec, const uint8_t *bytes, long cap, const int *nbytes,
+                              const float *mask, int b, float *code_out, int *err, lic360_impcodec *map_codec, long generation);
 
 /* ---- f3 viewport projection (ProjectsOp, the sampling stage of VPSNR / VSSIM) -------------------------------------------------
  * Sampling coordinates tf [14][h_out*w_out][2] = (x, y) in ERP pixels of the 14 rectilinear viewports (yaw theta*pi, pitch phi*pi, field

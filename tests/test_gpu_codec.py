@@ -223,6 +223,22 @@ def test_latent_decode_gated_behind_the_map_decode(G, MH, MW, B, seed):
         assert np.array_equal(mbuf.cpu().numpy(), mask)
         assert np.array_equal(out.cpu().numpy(), code * mask)
         mbuf.fill_(7.0)
+    # the gate is a one-time ticket: a gate used twice, a gate of an earlier step and a foreign mask buffer are errors,
+    # not a silent decode against whatever the re-recorded events and the buffer happen to hold
+    import lic360
+    with pytest.raises(lic360.Lic360Error, match="stale gate"):
+        fc.decode_async(mbuf, B, gate=gate)
+    with torch.cuda.stream(s_map):
+        old_gate = ic.decode_masked_async(B, mbuf, mask_channels=4 * G, stride=2)
+        new_gate = ic.decode_masked_async(B, mbuf, mask_channels=4 * G, stride=2)
+    with pytest.raises(lic360.Lic360Error, match="stale gate"):
+        fc.decode_async(mbuf, B, gate=old_gate)
+    with pytest.raises(lic360.Lic360Error, match="not the buffer"):
+        fc.decode_async(torch.zeros_like(mbuf), B, gate=new_gate)
+    with torch.cuda.stream(s_lat):
+        out = fc.decode_async(mbuf, B, gate=new_gate)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), code * mask)
 
 
 def test_fused_codec_corrupt_stream_is_reported_not_fatal():

@@ -47,12 +47,15 @@ for p in planes:
     t16 = run(L.lic360_cconv16_dc_plane, packed, p)
     line = "plane %3d: new %7.1f us" % (p, t16)
     if has_stamps:
-        buf = (C.c_ulonglong * (256 * 8 * 8))()
+        buf = (C.c_ulonglong * (256 * 8 * 10))()
         L.lic360_xd_stamps(buf, 0)
-        st = np.array(buf, dtype=np.float64).reshape(256, 8, 8) / 23.0          # per launch (3 warm-up + 20 timed)
+        st = np.array(buf, dtype=np.float64).reshape(256, 8, 10) / 23.0          # per launch (3 warm-up + 20 timed)
         tot = st.sum(-1)
-        line += "  | wave cycles/launch: total %6.0f (max wg %6.0f)  setup %5.0f  kloop %6.0f  eload+halo %5.0f  bar1 %5.0f  tree %5.0f  bar2 %5.0f  final %5.0f  exit %5.0f" % (
+        line += "  | wave cycles/launch: total %6.0f (max wg %6.0f)  setup %5.0f  kloop %6.0f  eload+halo %5.0f  bar1 %5.0f  tree %5.0f  bar2 %5.0f  final %5.0f  dmawait %5.0f  stagebar %5.0f  - %5.0f" % (
             tot.mean(), tot.mean(1).max(), *st.mean((0, 1)))
+    if has_stamps and os.environ.get("XWAVES"):
+        for wv in range(8):
+            line += "\n      wave (half %d, class %d): " % (wv >> 2, wv & 3) + " ".join("%7.0f" % v for v in st[:, wv, :].mean(0))
     t4 = run(L.lic360_cconv4_dc_plane, packed4, p)
     print(line + "   | old %7.1f us" % t4)
     tot16 += t16; tot4 += t4
