@@ -48,7 +48,10 @@
 #define XD_COL0 2
 #define XD_STAGE_A (XD_NT * 64)                // floats of packed weights per (class, K block)
 #define XD_STAGE (XD_STAGE_A + XD_ND * 256)   // + 11 input diagonals x (4 channel planes x 64 rows): 17 KB per (buffer, class)
-#define XD_NDMA 9                             // LDS-DMAs per wave and stage: 3 weight chunks + 6 diagonals (row half 1: the 6th repeats its 5th)
+#ifndef XD_SPLIT
+#define XD_SPLIT 0                            // 1: row half 0 issues all 17 LDS-DMAs of its class's next stage, half 1 none; 0: 9 + 8
+#endif
+#define XD_NDMA (XD_SPLIT ? 6 + XD_ND : 9)    // LDS-DMAs per issuing wave and stage (0: 3 weight chunks + 6 diagonals; row half 1: the 6th repeats its 5th)
 #ifndef XD_PF
 #define XD_PF 3                               // operand reads run this many diagonals ahead of their MFMAs
 #endif
@@ -239,8 +242,9 @@ LIC360_API int lic360_xd_stamps(unsigned long long *host_out, int clear) {
 #define XD_T(i)
 #endif
 
-template <int CLS>
-__device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *halo, float *comb, const int lane, const int whalf) {
+template <int CLS, int HALF>
+__device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *halo, float *comb, const int lane) {
+    constexpr int whalf = HALF;
     const int G = a.G, H = a.H, W = a.W, S = H + W - 1, C = G * 4, nout = G * a.cout, HP = a.HP;
     const long SKP = a.SKP;
     const int n16 = lane & 15, kl = lane >> 4;
@@ -337,10 +341,22 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *hal
     };
     const unsigned hp4 = (unsigned)HP * 4u, skp4 = (unsigned)SKP * 4u;
     const unsigned kbx = 16u * skp4;                                        // bytes between K blocks of x (< 2^32: one sample's planes)
-    // the 9 LDS-DMAs of one wave for one stage (weights of K block at wk, activations at xk) into the stage image at LDS byte `dst`:
-    // j < 3: weight chunk 3 half + j;  j >= 3: diagonal dc = 6 half + j - 3 (half 1: 6..10, the last one twice -- same bytes)
+    // the LDS-DMAs of one wave for one stage (weights of K block at wk, activations at xk) into the stage image at LDS byte `dst`
     auto dma_one = [&](auto jj, xd_gptr xk, xd_gptr wk, unsigned voff, unsigned dst) __attribute__((always_inline)) {
         constexpr int j = decltype(jj)::value;
+#if XD_SPLIT
+        // The two row halves of a class share a SIMD and the hardware arbitrates its issue winner-takes-all (by priority, then age): one
+        // of them runs ahead, the other finishes alone.  So the roles are made explicit: half 0 issues ALL the class's DMAs at the
+        // start of a stage, while half 1 -- at priority 1 -- has the matrix pipe to itself; half 0's MFMAs fill in behind.
+        if constexpr (HALF == 0) {
+            if constexpr (j < 6) xd_dma(lane16, wk + j * 1024u, dst + j * 1024u);
+            else {
+                constexpr int dc = j - 6;
+                constexpr unsigned gid = (unsigned)(CLS + XD_C0 + 16 - dc) & 3u;    // input channel inside a group: (class - c) mod 4, c = dc - XD_C0
+                xd_dma(voff, xk + ((unsigned)dc * hp4 + gid * skp4), dst + (unsigned)(XD_STAGE_A + dc * 256) * 4u);
+            }
+        }
+#else
         if constexpr (j < 3) {
             const unsigned ch = (3u * (unsigned)whalf + j) * 1024u;
             xd_dma(lane16, wk + ch, dst + ch);
@@ -350,6 +366,7 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *hal
             const unsigned gid = (unsigned)(CLS + XD_C0 + 16 - dc) & 3u;    // input channel inside a group: (class - c) mod 4, c = dc - XD_C0
             xd_dma(voff, xk + ((unsigned)dc * hp4 + gid * skp4), dst + (unsigned)(XD_STAGE_A + dc * 256) * 4u);
         }
+#endif
     };
     // ---- MFMA-side operand reads: lane (k, n) of half h reads its two rows (8 bytes) of plane k from slot 32 (k >> 1) + 16 h + 8 (k & 1) + (n >> 1)
     const int boff = 4 * (32 * (kl >> 1) + 16 * whalf + 8 * (kl & 1) + (n16 >> 1)) + 2 * (n16 & 1);   // floats inside a diagonal's 1 KB chunk
@@ -390,13 +407,14 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *hal
         const unsigned dst = xd_lds_addr(stage_image(stage + 1));
         auto hook = [&](auto mm) __attribute__((always_inline)) {
             constexpr int m = decltype(mm)::value;
-            if constexpr (m % XD_DSTRIDE == 0 && m / XD_DSTRIDE < XD_NDMA) {
+            if constexpr (XD_DSTRIDE > 0 && m % (XD_DSTRIDE > 0 ? XD_DSTRIDE : 1) == 0 && m / (XD_DSTRIDE > 0 ? XD_DSTRIDE : 1) < XD_NDMA) {
                 __builtin_amdgcn_sched_barrier(0);
                 dma_one(IC<m / XD_DSTRIDE>{}, xk1, wk1, voff1, dst);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         XdOps ops[XD_PF + 1];
+        if constexpr (XD_DSTRIDE == 0) static_for<XD_NDMA>([&](auto jj) { dma_one(jj, xk1, wk1, voff1, dst); });   // all of them up front
         static_for<(XD_PF < N ? XD_PF : N)>([&](auto ii) { load_ops(IC<xd_walk(N, decltype(ii)::value)>{}, ops[decltype(ii)::value], sA); });
         static_for<N>([&](auto ii) {
             constexpr int i = decltype(ii)::value, dc = xd_walk(N, i);
@@ -412,9 +430,8 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *hal
             fma(IC<dc>{}, IC<m0>{}, ops[i % (XD_PF + 1)], hook);
             __builtin_amdgcn_sched_barrier(0);
         });
-        static_for<((NM + XD_DSTRIDE - 1) / XD_DSTRIDE < XD_NDMA ? XD_NDMA - (NM + XD_DSTRIDE - 1) / XD_DSTRIDE : 0)>([&](auto rr) {
-            dma_one(IC<(NM + XD_DSTRIDE - 1) / XD_DSTRIDE + decltype(rr)::value>{}, xk1, wk1, voff1, dst);
-        });
+        constexpr int HOOKED = XD_DSTRIDE > 0 ? (NM + (XD_DSTRIDE > 0 ? XD_DSTRIDE : 1) - 1) / (XD_DSTRIDE > 0 ? XD_DSTRIDE : 1) : XD_NDMA;   // DMAs the hooks issued
+        static_for<(HOOKED < XD_NDMA ? XD_NDMA - HOOKED : 0)>([&](auto rr) { dma_one(IC<HOOKED + decltype(rr)::value>{}, xk1, wk1, voff1, dst); });
         XD_T(1);
         XD_WAIT0();
         XD_T(7);                                                            // (diagnostic build: the wait for this wave's own DMAs ...
@@ -592,7 +609,7 @@ __device__ __forceinline__ void xd_body(const XdArgs &a, float *ring, float *hal
     }
 #ifdef XD_STAMP
     if (lane == 0) {
-        for (int i = 0; i < 10; ++i) xd_stamps[((blockIdx.x & 255) * 8 + whalf * 4 + CLS) * 10 + i] += st[i];
+        for (int i = 0; i < 10; ++i) xd_stamps[((blockIdx.x & 255) * 8 + HALF * 4 + CLS) * 10 + i] += st[i];
     }
 #endif
 }
@@ -612,11 +629,15 @@ __global__ __launch_bounds__(XD_THREADS, 2) void k_cconv16dc(XdArgs a) {
     // younger half (MI355X_MICROARCH.md, "Two waves per SIMD", item 4).
     if (half) __builtin_amdgcn_s_setprio(1);
 #endif
-    switch (cls) {
-        case 0: xd_body<0>(a, ring, halo, comb, lane, half); break;
-        case 1: xd_body<1>(a, ring, halo, comb, lane, half); break;
-        case 2: xd_body<2>(a, ring, halo, comb, lane, half); break;
-        default: xd_body<3>(a, ring, halo, comb, lane, half); break;
+    switch (wave) {
+        case 0: xd_body<0, 0>(a, ring, halo, comb, lane); break;
+        case 1: xd_body<1, 0>(a, ring, halo, comb, lane); break;
+        case 2: xd_body<2, 0>(a, ring, halo, comb, lane); break;
+        case 3: xd_body<3, 0>(a, ring, halo, comb, lane); break;
+        case 4: xd_body<0, 1>(a, ring, halo, comb, lane); break;
+        case 5: xd_body<1, 1>(a, ring, halo, comb, lane); break;
+        case 6: xd_body<2, 1>(a, ring, halo, comb, lane); break;
+        default: xd_body<3, 1>(a, ring, halo, comb, lane); break;
     }
 }
 
