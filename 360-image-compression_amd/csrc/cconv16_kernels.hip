@@ -175,7 +175,9 @@ __device__ __forceinline__ void c16_load4(C16Ops &o, const float *xs, const floa
 // a partner's MFMAs do not cover a wave's LDS latency); sched_barriers pin that order -- left alone, the scheduler hoists every
 // read of the range above the first MFMA and spills the accumulators.  ops[] is a ring indexed by the chain's position g in
 // the step (ranges back to back); chains of the NEXT range are prefetched when that range runs (`more`).
+#ifndef C16_PF
 #define C16_PF 2
+#endif
 __host__ __device__ constexpr int c16_range_base(int R) { return R == 0 ? 0 : (R == 1 ? 10 : 19); }
 template <int CLS, int R, bool FIRST, class Hook>
 __device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, const float *ws, C16Ops (&ops)[C16_PF + 1], bool more, Hook &&hook) {
@@ -518,6 +520,9 @@ __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
     __shared__ int tq[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef C16_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);                           // (experiment) static priority for the younger wave of every SIMD
+#endif
     switch (wave) {
         case 0: c16_body<CIN, 0, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
         case 1: c16_body<CIN, 1, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
