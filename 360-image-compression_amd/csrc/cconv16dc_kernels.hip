@@ -678,3 +678,405 @@ LIC360_API int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *p, 
     LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================ class-sequential form (round 4)
+// k_cconv16dq: the same mapping, arithmetic, packed weights and LDS-DMA stages as k_cconv16dc, with the work of a task laid out in TIME
+// instead of over waves.  In k_cconv16dc the eight waves of a workgroup are 4 lane classes x 2 row halves of one (sample, group block): they
+// run in lockstep (a barrier per stage, two per task), the two waves of a SIMD are the two halves of one class -- and the hardware
+// arbitrates a SIMD's issue winner-takes-all, so one half runs ahead and waits at every barrier while the other finishes alone at a
+// lone wave's pace (stamps, profiles/r04_dc16_ldsdma_counters.txt: 17 % of a wave's time in stage barriers, the matrix pipe 53 % busy).
+// Here a workgroup has FOUR waves = 2 samples x 2 row halves (or 4 samples where a block's diagonals fit 32 rows) of one group block,
+// and every wave walks the four lane classes one after the other on the same 192 accumulators:
+//   * two workgroups per CU: the two waves of a SIMD belong to DIFFERENT workgroups (or kernels of different streams), drift apart, and
+//     the epilogue / barrier / stage-start bubbles of one are filled with the other's MFMAs;
+//   * the packed weights of a stage are shared by the workgroup's four waves (28 LDS-DMAs per stage and workgroup: 6 + 2 x 11);
+//   * no class combine through LDS: a wave meets all four class partials of its outputs itself, (F0 + F2) + (F1 + F3) in registers;
+//     what is left between waves is the halo of the two row halves of a sample, once per class pass.
+#define XQ_THREADS 256
+#define XQ_IMG (XD_STAGE_A + 2 * XD_ND * 256)  // floats of one stage image: weights | input diagonals of wave pair 0 | of wave pair 1 (28 KB)
+#ifndef XQ_PF
+#define XQ_PF 2
+#endif
+#ifndef XQ_DSTRIDE
+#define XQ_DSTRIDE 2
+#endif
+
+template <int WV>
+__device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *halo, float *hs_all, const int lane) {
+    float *const hs = hs_all + WV * (XD_GB * 2 * 2 * 64) + lane;            // this lane's class partials [group][output row][class parity] (LDS: 12 registers too many)
+    constexpr int PAIR = WV >> 1, HALF = WV & 1;                            // wave = (sample slot pair, row half)
+    constexpr int NA_DMA = WV < 2 ? 2 : 1, NB_DMA = HALF ? XD_ND - 6 : 6, NDMA = NA_DMA + NB_DMA;   // this wave's share of a stage's 28 DMAs
+    const int G = a.G, H = a.H, W = a.W, S = H + W - 1, C = G * 4, nout = G * a.cout, HP = a.HP;
+    const long SKP = a.SKP;
+    const int n16 = lane & 15, kl = lane >> 4;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x - xcd + 7) >> 3;
+    const int spn = a.npb >> 3;                                             // samples per stacked net and XCD (host: 8 | npb, 8 | N): n = xcd + 8 i
+    const int nb = a.N / a.npb;
+    auto window_of = [&](int gb) __attribute__((always_inline)) {             // as in xd_body
+        int lo = 1 << 30, hi = -1;
+#pragma unroll
+        for (int q = 0; q < XD_GB; ++q) {
+            const int g = gb * XD_GB + q, sq = a.psum - g;
+            const int l = sq >= W ? sq - W + 1 : 0, hh = sq < H ? sq : H - 1;
+            if (g < G && sq >= 0 && sq < S) { lo = l < lo ? l : lo; hi = hh > hi ? hh : hi; }
+        }
+        const int lo_in = lo - 2 > 0 ? lo - 2 : 0, hi_in = hi + 2 < H - 1 ? hi + 2 : H - 1, t0 = lo_in & ~1;
+        return hi_in - t0 + 1 <= 32 ? t0 : -1;
+    };
+    unsigned span_mask = 0;                                                 // bit j: block gb_hi - j has 64-row diagonals: 2 samples per task (else 4)
+    for (int j = 0; j < a.n_gbv; ++j) span_mask |= (window_of(a.gb_hi - j) < 0 ? 1u : 0u) << j;
+    span_mask = __builtin_amdgcn_readfirstlane(span_mask);
+    const int upn_span = (spn + 1) >> 1, upn_pair = (spn + 3) >> 2;          // tasks per net and group block
+    auto units_of = [&](int j) __attribute__((always_inline)) { return nb * (((span_mask >> j) & 1u) ? upn_span : upn_pair); };
+    int n_my = 0;
+    for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
+    const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#ifdef XD_STAMP
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+#endif
+    struct Task {
+        int tc0, s0, n_w, net, pbase, X, nKmax, gb;
+        unsigned d0, d1;
+        bool span, valid_w;
+        xd_gptr xs, ws;                                                     // ws: packed weights of (net, group block), class 0
+    };
+    int scan_j = 0, scan_base = 0;
+    auto decode = [&](int kt, Task &t) __attribute__((always_inline)) {
+        const int u = kt * wgs_per_xcd + ((kt & 1) ? wgs_per_xcd - 1 - wg_in_xcd : wg_in_xcd);
+        if (u >= n_my) return false;
+        while (scan_j < a.n_gbv - 1 && u >= scan_base + units_of(scan_j)) { scan_base += units_of(scan_j); ++scan_j; }   // (u grows with kt)
+        const int gb = a.gb_hi - scan_j;
+        t.span = (span_mask >> scan_j) & 1u;
+        const int upn = t.span ? upn_span : upn_pair;
+        int rem = u - scan_base, net = 0;
+        while (rem >= upn) { rem -= upn; ++net; }
+        t.net = net; t.gb = gb;
+        t.tc0 = gb * XD_GB; t.s0 = a.psum - t.tc0;
+        const int T0 = t.span ? 0 : window_of(gb);
+        // samples of this wave pair's two row halves (index inside the net's list of the XCD; a slot past the list recomputes the
+        // unit's first sample and stores nothing)
+        int jA, jB;
+        if (t.span) { jA = jB = 2 * rem + PAIR; }
+        else { jA = 4 * rem + 2 * PAIR; jB = jA + 1; }
+        const bool vA = jA < spn, vB = jB < spn;
+        const int j0 = t.span ? 2 * rem : 4 * rem;
+        if (!vA) jA = j0;
+        if (!vB) jB = vA ? jA : j0;
+        const int nA = xcd + 8 * (net * spn + jA), nB = xcd + 8 * (net * spn + jB);
+        t.n_w = HALF ? nB : nA;
+        t.valid_w = HALF ? vB : vA;
+        t.pbase = T0 + (t.span ? 32 * HALF : 0);
+        t.X = t.tc0 + 4 + a.hidden + XD_C0;
+        t.nKmax = ((t.X < G ? t.X : G) + 3) >> 2;
+        const int iA = nA < a.x_mod ? nA : nA % a.x_mod, iB = nB < a.x_mod ? nB : nB % a.x_mod, i0 = iA < iB ? iA : iB;
+        const long sample_bytes = (long)C * SKP * 4;
+        t.d0 = (unsigned)((iA - i0) * sample_bytes); t.d1 = (unsigned)((iB - i0) * sample_bytes);
+        t.xs = (xd_gptr)(a.x + (long)i0 * C * SKP + (long)t.s0 * HP + XD_COL0);
+        t.ws = (xd_gptr)(a.packed + (((long)net * a.ngb_all + gb) * 4 * a.NKB) * XD_STAGE_A);
+        return true;
+    };
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma_lane_offset = [&](const Task &t) __attribute__((always_inline)) -> unsigned {        // as in xd_body: the pair's 64 rows of one diagonal
+        const int h = (lane >> 4) & 1, k = 2 * (lane >> 5) + ((lane >> 3) & 1), m = lane & 7;
+        int r = (t.span ? 32 * h : t.pbase) + 4 * m;
+        if (r >= H + 2) r = H - 2 > 0 ? H - 2 : 0;
+        return (unsigned)((4 * k * (int)SKP + r) * 4) + (h ? t.d1 : t.d0);
+    };
+    const unsigned hp4 = (unsigned)HP * 4u, skp4 = (unsigned)SKP * 4u, kbx = 16u * skp4;
+    const unsigned cls_bytes = (unsigned)a.NKB * (XD_STAGE_A * 4);          // packed weights of one class of a (net, group block)
+    // DMA j of this wave for the stage (class cn, weights at wk, activations at xk): j < NA_DMA: weight chunk WV + 4 j; else the pair's
+    // diagonal 6 HALF + j - NA_DMA
+    auto dma_one = [&](auto jj, xd_gptr xk, xd_gptr wk, int cn, unsigned voff, unsigned dst) __attribute__((always_inline)) {
+        constexpr int j = decltype(jj)::value;
+        if constexpr (j < NA_DMA) {
+            constexpr unsigned ch = (unsigned)(WV + 4 * j) * 1024u;
+            xd_dma(lane16, wk + ch, dst + ch);
+        } else {
+            constexpr int dc = 6 * HALF + (j - NA_DMA);
+            const unsigned gid = (unsigned)(cn + XD_C0 + 16 - dc) & 3u;
+            xd_dma(voff, xk + ((unsigned)dc * hp4 + gid * skp4), dst + (unsigned)(XD_STAGE_A + (PAIR * XD_ND + dc) * 256) * 4u);
+        }
+    };
+    const int boff = XD_STAGE_A + PAIR * XD_ND * 256 + 4 * (32 * (kl >> 1) + 16 * HALF + 8 * (kl & 1) + (n16 >> 1)) + 2 * (n16 & 1);
+    f32x4 acc[XD_NT][2];
+    auto load_ops = [&](auto dd, XdOps &o, const float *sA) __attribute__((always_inline)) {
+        constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
+        const float *p = sA + tb * 64;
+        if constexpr (T == 1) o.a[0] = p[lane];
+        else if constexpr (T == 2) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; }
+        else if constexpr (T == 3) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; o.a[2] = p[128 + lane]; }
+        else { const f32x4 v = *(const f32x4 *)(p + 4 * lane); o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3]; }
+        o.b = *(const xd_f2 *)(sA + dc * 256 + boff);
+    };
+    auto fma = [&](auto dd, auto mm0, const XdOps &o, auto &&hook) __attribute__((always_inline)) {
+        constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc), M0 = decltype(mm0)::value;
+        static_for<T>([&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, acc[tb + t][0]);
+            hook(IC<M0 + 2 * t>{});
+            acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, acc[tb + t][1]);
+            hook(IC<M0 + 2 * t + 1>{});
+        });
+    };
+    unsigned stage = 0;
+    auto stage_image = [&](unsigned par) __attribute__((always_inline)) { return ring + (par & 1u) * XQ_IMG; };
+    auto body = [&](auto NN, xd_gptr xk1, xd_gptr wk1, int cn1, unsigned voff1) __attribute__((always_inline)) {
+        constexpr int N = decltype(NN)::value, NM = 2 * xd_tbase(N);
+        const float *sA = stage_image(stage);
+        const unsigned dst = xd_lds_addr(stage_image(stage + 1));
+        auto hook = [&](auto mm) __attribute__((always_inline)) {
+            constexpr int m = decltype(mm)::value;
+            if constexpr (m % XQ_DSTRIDE == 0 && m / XQ_DSTRIDE < NDMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_one(IC<m / XQ_DSTRIDE>{}, xk1, wk1, cn1, voff1, dst);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        XdOps ops[XQ_PF + 1];
+        static_for<(XQ_PF < N ? XQ_PF : N)>([&](auto ii) { load_ops(IC<xd_walk(N, decltype(ii)::value)>{}, ops[decltype(ii)::value], sA); });
+        static_for<N>([&](auto ii) {
+            constexpr int i = decltype(ii)::value, dc = xd_walk(N, i);
+            constexpr int m0 = [] { int m = 0; for (int j = 0; j < i; ++j) m += 2 * xd_ntiles(xd_walk(N, j)); return m; }();
+            if constexpr (i + XQ_PF < N) load_ops(IC<xd_walk(N, i + XQ_PF)>{}, ops[(i + XQ_PF) % (XQ_PF + 1)], sA);
+            __builtin_amdgcn_sched_barrier(0);
+            fma(IC<dc>{}, IC<m0>{}, ops[i % (XQ_PF + 1)], hook);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        constexpr int HOOKED = (NM + XQ_DSTRIDE - 1) / XQ_DSTRIDE;
+        static_for<(HOOKED < NDMA ? NDMA - HOOKED : 0)>([&](auto rr) { dma_one(IC<HOOKED + decltype(rr)::value>{}, xk1, wk1, cn1, voff1, dst); });
+        XD_T(1);
+        XD_WAIT0();
+        XD_T(7);
+        __syncthreads();
+        XD_T(8);
+        ++stage;
+    };
+    Task cur, nxt;
+    if (!decode(0, cur)) return;                                            // (uniform over the workgroup)
+    unsigned voff = dma_lane_offset(cur);
+    {
+        const unsigned dst = xd_lds_addr(stage_image(0));
+        static_for<NDMA>([&](auto jj) { dma_one(jj, cur.xs, cur.ws, 0, voff, dst); });
+        XD_WAIT0();
+        __syncthreads();
+    }
+    for (int kt = 0;; ++kt) {
+        const int tc0 = cur.tc0, s0 = cur.s0, n_w = cur.n_w, net = cur.net, pbase = cur.pbase;
+        const bool span = cur.span, valid_w = cur.valid_w;
+        const bool have_next = decode(kt + 1, nxt);
+        const unsigned voff_n = have_next ? dma_lane_offset(nxt) : voff;
+#ifndef XQ_NCLS
+#define XQ_NCLS 4
+#endif
+        static_for<XQ_NCLS>([&](auto cc) {
+            constexpr int CLS = decltype(cc)::value;
+#pragma unroll
+            for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
+            XD_T(0);
+            {
+                xd_gptr xk = cur.xs, wk = cur.ws + (unsigned)CLS * cls_bytes;
+                const int X = cur.X;
+                int nKmax = cur.nKmax;
+                asm volatile("" : "+s"(nKmax));
+                int kb = 0, D = X;
+                // the stage after block kb of class CLS: block kb + 1; or block 0 of the next class; or of the next task's class 0 (none: itself)
+                auto next_stage = [&](xd_gptr &xk1, xd_gptr &wk1, int &cn1, unsigned &v1) __attribute__((always_inline)) {
+                    const bool inner = kb + 1 < nKmax;
+                    if constexpr (CLS < 3) {
+                        xk1 = inner ? xk + kbx : cur.xs;
+                        wk1 = inner ? wk + (unsigned)(XD_STAGE_A * 4) : cur.ws + (unsigned)(CLS + 1) * cls_bytes;
+                        cn1 = inner ? CLS : CLS + 1;
+                        v1 = voff;
+                    } else {
+                        xk1 = inner ? xk + kbx : (have_next ? nxt.xs : xk);
+                        wk1 = inner ? wk + (unsigned)(XD_STAGE_A * 4) : (have_next ? nxt.ws : wk);
+                        cn1 = inner || !have_next ? CLS : 0;
+                        v1 = inner ? voff : voff_n;
+                    }
+                    cn1 = __builtin_amdgcn_readfirstlane(cn1);
+                    asm volatile("" : "+s"(xk1), "+s"(wk1));
+                };
+                for (; kb < nKmax && D >= 8; ++kb, D -= 4) {
+                    xd_gptr xk1, wk1; int cn1; unsigned v1;
+                    next_stage(xk1, wk1, cn1, v1);
+                    body(IC<XD_ND>{}, xk1, wk1, cn1, v1);
+                    xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4);
+                }
+                if (kb < nKmax && D >= 4) {
+                    xd_gptr xk1, wk1; int cn1; unsigned v1;
+                    next_stage(xk1, wk1, cn1, v1);
+                    body(IC<7>{}, xk1, wk1, cn1, v1);
+                    xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4); ++kb; D -= 4;
+                }
+                if (kb < nKmax) {
+                    xd_gptr xk1, wk1; int cn1; unsigned v1;
+                    next_stage(xk1, wk1, cn1, v1);
+                    body(IC<3>{}, xk1, wk1, cn1, v1);
+                }
+            }
+            // ---- halo of the two row halves of a sample (span tasks), then realignment + the reference tree inside the class
+            if (span) {
+                if constexpr (HALF == 1) {
+                    if (n16 == 0) {
+                        static_for<XD_ND>([&](auto dd) {
+                            constexpr int dc = decltype(dd)::value;
+                            static_for<xd_nslots(dc)>([&](auto ii) {
+                                constexpr int idx = decltype(ii)::value, kh = xd_slot(dc, idx) & 7, tile = xd_tbase(dc) + idx / 4, reg = idx & 3;
+                                static_for<2>([&](auto tt) {
+                                    constexpr int t = decltype(tt)::value;
+                                    if constexpr (xd_halo_has(kh, t, true)) {
+                                        constexpr int hid = ((1 * 2 + PAIR) * XD_NHALO + xd_halo_id(dc, idx, t, true)) * 4;
+                                        halo[hid + kl] = acc[tile][t][reg];
+                                    }
+                                });
+                            });
+                        });
+                    }
+                } else {
+                    if (n16 == 15) {
+                        static_for<XD_ND>([&](auto dd) {
+                            constexpr int dc = decltype(dd)::value;
+                            static_for<xd_nslots(dc)>([&](auto ii) {
+                                constexpr int idx = decltype(ii)::value, kh = xd_slot(dc, idx) & 7, tile = xd_tbase(dc) + idx / 4, reg = idx & 3;
+                                static_for<2>([&](auto tt) {
+                                    constexpr int t = decltype(tt)::value;
+                                    if constexpr (xd_halo_has(kh, t, false)) {
+                                        constexpr int hid = ((0 * 2 + PAIR) * XD_NHALO + xd_halo_id(dc, idx, t, false)) * 4;
+                                        halo[hid + kl] = acc[tile][t][reg];
+                                    }
+                                });
+                            });
+                        });
+                    }
+                }
+                XD_T(2);
+                __syncthreads();
+                XD_T(3);
+            }
+            const float *const halo_up = halo + ((span && HALF == 0) ? (1 * 2 + PAIR) * XD_NHALO * 4 : 2 * 2 * XD_NHALO * 4) + kl;
+            const float *const halo_dn = halo + ((span && HALF == 1) ? (0 * 2 + PAIR) * XD_NHALO * 4 : 2 * 2 * XD_NHALO * 4) + kl;
+            static_for<XD_GB>([&](auto qq) {
+                constexpr int Q = decltype(qq)::value, CQ = (CLS + Q) & 3;
+                static_for<2>([&](auto tt) {
+                    constexpr int TP = decltype(tt)::value;
+                    auto leaf = [&](auto ii) __attribute__((always_inline)) -> float {
+                        constexpr int i = decltype(ii)::value, tap = i % 25, kh = tap / 5, kw = tap % 5, c = kh + kw - Q, dc = c + XD_C0;
+                        static_assert(dc >= 0 && dc < XD_ND && ((CLS - c + 16) & 3) == i / 25, "leaf i of class CQ lies on diagonal c in channel gid");
+                        constexpr int idx = xd_slot_index(dc, Q, kh), tile = xd_tbase(dc) + idx / 4, reg = idx & 3, dl = kh - 2;
+                        static_assert(idx >= 0, "slot table");
+                        if constexpr (dl == 0) return acc[tile][TP][reg];
+                        else if constexpr (dl == 1 && TP == 0) return acc[tile][1][reg];
+                        else if constexpr (dl == -1 && TP == 1) return acc[tile][0][reg];
+                        else if constexpr (dl > 0) {
+                            constexpr int TS = dl == 1 ? 0 : TP, hid = xd_halo_id(dc, idx, TS, true) * 4;
+                            const float e = halo_up[hid];
+                            return xd_row_shift<XD_ROW_SHL1>(e, acc[tile][TS][reg]);
+                        } else {
+                            constexpr int TS = dl == -1 ? 1 : TP, hid = xd_halo_id(dc, idx, TS, false) * 4;
+                            const float e = halo_dn[hid];
+                            return xd_row_shift<XD_ROW_SHR1>(e, acc[tile][TS][reg]);
+                        }
+                    };
+                    __builtin_amdgcn_sched_barrier(0);                          // (else hipcc hoists every tree's halo reads and spills accumulators)
+                    const float part = XdTree<CQ, 4>::eval(leaf);               // F(CQ, 4) of group Q
+                    // class order of group Q over the passes: Q, Q+1, Q+2, Q+3 (mod 4): the second class of a parity adds to the first
+                    constexpr int hi = ((Q * 2 + TP) * 2 + (CQ & 1)) * 64;
+                    if constexpr (CLS < 2) hs[hi] = part;
+                    else hs[hi] = hs[hi] + part;                                // F0 + F2 / F1 + F3 (IEEE addition commutes exactly)
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        });
+        XD_T(4);
+        // ---- (F0 + F2) + (F1 + F3) + bias / PReLU / residual / store: this wave's two rows of channel o = lane >> 4 of the three groups
+        {
+            const int pe_e = pbase + 2 * n16, o = kl;
+            const int pc = pe_e > ((H + 1) & ~1) ? ((H + 1) & ~1) : pe_e;
+            static_for<XD_GB>([&](auto qq) {
+                constexpr int Q = decltype(qq)::value;
+                const int g = tc0 + Q, sq = s0 - Q;
+                const bool vq = valid_w && g < G && sq >= 0 && sq < S && o < a.cout;
+                const int lo = sq >= W ? sq - W + 1 : 0, hi = sq < H ? sq : H - 1;
+                const bool ok0 = vq && pe_e >= lo && pe_e <= hi, ok1 = vq && pe_e + 1 >= lo && pe_e + 1 <= hi;
+                if (ok0 || ok1) {
+                    const int bid = net * nout + g * a.cout + o;
+                    const long oi = ((long)n_w * nout + g * a.cout + o) * SKP + (long)(sq + XD_ROW0) * HP + pc + XD_COL0;
+                    const float e_bias = a.bias[bid], e_act = act_p[bid];
+                    xd_f2 e_res = {0.f, 0.f};
+                    if (a.residual) e_res = *(const xd_f2u *)(res_p + oi);
+                    float sv[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float v = (hs[((Q * 2 + t) * 2 + 0) * 64] + hs[((Q * 2 + t) * 2 + 1) * 64]) + e_bias;
+                        if (a.act) { if (v < 0) v = v * e_act; }                  // cconv_dc_cuda.cu:360-362
+                        if (a.residual) v = v + (t == 0 ? e_res.x : e_res.y);    // fused TileAdd
+                        sv[t] = v;
+                    }
+                    if (ok0 && ok1) *(xd_f2u *)(a.out + oi) = (xd_f2u){sv[0], sv[1]};
+                    else if (ok0) a.out[oi] = sv[0];
+                    else a.out[oi + 1] = sv[1];
+                }
+            });
+        }
+        XD_T(6);
+        if (!have_next) break;
+        cur = nxt;
+        voff = voff_n;
+    }
+#ifdef XD_STAMP
+    if (lane == 0) for (int i = 0; i < 10; ++i) xd_stamps[((blockIdx.x & 255) * 8 + (blockIdx.x >> 8) * 4 + WV) * 10 + i] += st[i];
+#endif
+}
+
+__global__ __launch_bounds__(XQ_THREADS, 2) void k_cconv16dq(XdArgs a) {
+    __shared__ __attribute__((aligned(16))) float ring[2 * XQ_IMG];          // two stage images: 56 KB
+    __shared__ float halo[(2 * 2 + 1) * XD_NHALO * 4];                      // [direction][wave pair][register][channel] + a block of zeros
+    __shared__ float hs[4 * XD_GB * 2 * 2 * 64];                            // [wave][group][output row][class parity][lane]
+    for (int i = threadIdx.x; i < XD_NHALO * 4; i += XQ_THREADS) halo[2 * 2 * XD_NHALO * 4 + i] = 0.f;
+    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    switch (wave) {
+        case 0: xq_body<0>(a, ring, halo, hs, lane); break;
+        case 1: xq_body<1>(a, ring, halo, hs, lane); break;
+        case 2: xq_body<2>(a, ring, halo, hs, lane); break;
+        default: xq_body<3>(a, ring, halo, hs, lane); break;
+    }
+}
+
+// Same contract as lic360_cconv16_dc_plane; additionally 8 | n and 16 | n / nb and x_mod == n (the samples of a task share a net and sit
+// 8 apart): returns 3 when the shape does not qualify (the caller falls back to lic360_cconv16_dc_plane).
+LIC360_API int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
+                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
+    ARG_CHECK(p && conv16dc_ok(p) && x && packed && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n && h > 0 && h <= 64 && w > 0);
+    if (n % 8 || (n / nb) % 16 || x_mod != n) return 3;
+    const int G = p->ngroup, S = h + w - 1;
+    if (psum < 0 || psum >= h + w + G - 2) return 0;
+    int rows, pitch, row0, col0;
+    if (lic360_dc4_layout(h, w, &rows, &pitch, &row0, &col0)) return 2;
+    ARG_CHECK(row0 == XD_ROW0 && col0 == XD_COL0);
+    ARG_CHECK(8L * G * 4 * rows * pitch * 4 < (1L << 32));
+    XdArgs a;
+    a.x = x; a.packed = packed; a.bias = bias; a.act = act; a.residual = residual; a.out = out;
+    a.G = G; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w; a.npb = n / nb; a.x_mod = x_mod; a.N = n; a.psum = psum;
+    a.ngb_all = conv16dc_ngb(p); a.NKB = conv16dc_nkb(p); a.HP = pitch; a.SKP = (long)rows * pitch;
+    a.can_pair = 1; a.rs = 0;
+    int gb_lo = 1 << 30, gb_hi = -1;
+    for (int gb = 0; gb < a.ngb_all; ++gb) {
+        bool live = false;
+        for (int q = 0; q < XD_GB; ++q) {
+            const int g = gb * XD_GB + q, sq = psum - g;
+            live = live || (g < G && sq >= 0 && sq < S);
+        }
+        if (!live) continue;
+        if (gb < gb_lo) gb_lo = gb;
+        if (gb > gb_hi) gb_hi = gb;
+    }
+    if (gb_hi < 0) return 0;
+    a.gb_hi = gb_hi; a.n_gbv = gb_hi - gb_lo + 1;
+    ARG_CHECK(a.n_gbv <= 32);
+    hipLaunchKernelGGL(k_cconv16dq, dim3(512), dim3(XQ_THREADS), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -211,6 +211,12 @@ long lic360_conv16dc_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv16dc_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16dc);
 int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
                             const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
+/* The same plane, same arithmetic and same packed weights on 4-wave workgroups that walk the four lane classes of a task one after the
+ * other (two independent workgroups per CU, no class combine through LDS).  Needs 8 | n, 16 | n / nb and x_mod == n (the two / four
+ * samples of a task share a net and lie 8 apart in n); returns 3 -- nothing launched -- for other batches: call
+ * lic360_cconv16_dc_plane then.  Replaces the same reference call (extension/cconv_dc_cuda.cu:313-398). */
+int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
+                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
 
 /* Last layer of the latent entropy model with the CDF-table build fused into its epilogue (SURVEY.md §7 k_cconv_ec_last_gmm;
  * replaces the last CconvEcBatch.forward + TileExtractBatch + EntropyBatchGmmTable.forward_batch of

@@ -1010,6 +1010,20 @@ def test_cconv16_last_layer_with_fused_tables(lic, G, B, H, W):
                                   (16, 4, True, True, 1, 17, 50, 30)],
                          ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
 def test_cconv16_dc_planes_bit_exact(lic, case):
+    _cconv16_dc_planes(lic, case, "lic360_cconv16_dc_plane")
+
+
+@pytest.mark.parametrize("case", [(48, 4, True, True, 3, 48, 8, 16), (48, 3, True, False, 3, 48, 64, 20), (12, 4, True, True, 1, 16, 64, 9),
+                                  (8, 4, True, True, 1, 48, 40, 12), (4, 3, True, False, 2, 96, 30, 6), (16, 4, True, True, 1, 32, 50, 30),
+                                  (8, 4, False, True, 3, 144, 33, 21)],
+                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
+def test_cconv16_dq_planes_bit_exact(lic, case):
+    """the class-sequential form (4-wave workgroups: two samples on 64 rows or four on 32-row windows per task, the lane classes one
+    after the other): 16 | samples per net; three samples per net and XCD (odd: a task with an idle slot), 6 (4 + 2), short and full diagonals"""
+    _cconv16_dc_planes(lic, case, "lic360_cconv16_dq_plane")
+
+
+def _cconv16_dc_planes(lic, case, entry):
     """lic360_cconv16_dc_plane (hidden / last layers of the latent nets in decode order: MFMA columns = input rows of one input
     anti-diagonal) on the lic360_dc4_layout: after every checked plane the persistent output equals the oracle's
     (extension/cconv_dc_cuda.cu:313-398) + residual; covers one sample per task on 64 rows, two samples per task on 32 rows
@@ -1059,7 +1073,7 @@ def test_cconv16_dc_planes_bit_exact(lic, case):
     # x is complete from the start (the encoder's view of the same data): the causal rule decides what a plane may read
     for p in range(nplanes):
         orc.cconv_dc_plane(x, w, b, a, ref, G, constrain, idx, pidx, p)
-        assert L.lic360_cconv16_dc_plane(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, p, N) == 0, L.lic360_last_error()
+        assert getattr(L, entry)(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, p, N) == 0, L.lic360_last_error()
         if p in check:
             got = host(out)[:N * nout * rows * pitch].reshape(N, nout, rows, pitch)
             g = np.arange(G).repeat(cout)[None, :, None, None]

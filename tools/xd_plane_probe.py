@@ -44,7 +44,7 @@ tot16 = tot4 = 0.0
 for p in planes:
     if has_stamps:
         L.lic360_xd_stamps.argtypes = [C.c_void_p, C.c_int]; L.lic360_xd_stamps(None, 1)
-    t16 = run(L.lic360_cconv16_dc_plane, packed, p)
+    t16 = run(getattr(L, os.environ.get("XENTRY", "lic360_cconv16_dc_plane")), packed, p)
     line = "plane %3d: new %7.1f us" % (p, t16)
     if has_stamps:
         buf = (C.c_ulonglong * (256 * 8 * 10))()
