@@ -204,6 +204,11 @@ __device__ __forceinline__ float xd_row_shift(float edge, float v) {     // lane
 // before the barrier that publishes a stage).  M0 is written in the statement that reads it.
 typedef const __attribute__((address_space(1))) char *xd_gptr;            // (explicitly global: a pointer that went through asm would be flat)
 __device__ __forceinline__ void xd_dma(unsigned voff, xd_gptr sbase, unsigned lds) {
+    // (the base is wave-uniform by construction; where hipcc cannot prove it -- it keeps such a value in a VGPR -- the two
+    // v_readfirstlane make it so; where it can, they fold away)
+    const unsigned long long pb = (unsigned long long)sbase;
+    sbase = (xd_gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pb));
+    lds = (unsigned)__builtin_amdgcn_readfirstlane((int)lds);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 #define XD_WAIT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -727,9 +732,17 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
     for (int j = 0; j < a.n_gbv; ++j) span_mask |= (window_of(a.gb_hi - j) < 0 ? 1u : 0u) << j;
     span_mask = __builtin_amdgcn_readfirstlane(span_mask);
     const int upn_span = (spn + 1) >> 1, upn_pair = (spn + 3) >> 2;          // tasks per net and group block
+#ifdef XQ_NETMAJOR                                                            // (experiment) walk net by net: the bands of a net's 6 samples stay in L2
+    auto units_of = [&](int j) __attribute__((always_inline)) { return ((span_mask >> j) & 1u) ? upn_span : upn_pair; };
+    int per_net = 0;
+    for (int j = 0; j < a.n_gbv; ++j) per_net += units_of(j);
+    const int n_my = per_net * nb;
+    int wnet = 0;
+#else
     auto units_of = [&](int j) __attribute__((always_inline)) { return nb * (((span_mask >> j) & 1u) ? upn_span : upn_pair); };
     int n_my = 0;
     for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
+#endif
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #ifdef XD_STAMP
@@ -745,12 +758,19 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
     auto decode = [&](int kt, Task &t) __attribute__((always_inline)) {
         const int u = kt * wgs_per_xcd + ((kt & 1) ? wgs_per_xcd - 1 - wg_in_xcd : wg_in_xcd);
         if (u >= n_my) return false;
+#ifdef XQ_NETMAJOR
+        while (u >= (wnet + 1) * per_net) { ++wnet; scan_j = 0; scan_base = wnet * per_net; }
+#endif
         while (scan_j < a.n_gbv - 1 && u >= scan_base + units_of(scan_j)) { scan_base += units_of(scan_j); ++scan_j; }   // (u grows with kt)
         const int gb = a.gb_hi - scan_j;
         t.span = (span_mask >> scan_j) & 1u;
         const int upn = t.span ? upn_span : upn_pair;
         int rem = u - scan_base, net = 0;
+#ifdef XQ_NETMAJOR
+        net = wnet;
+#else
         while (rem >= upn) { rem -= upn; ++net; }
+#endif
         t.net = net; t.gb = gb;
         t.tc0 = gb * XD_GB; t.s0 = a.psum - t.tc0;
         const int T0 = t.span ? 0 : window_of(gb);
@@ -809,20 +829,26 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
         else { const f32x4 v = *(const f32x4 *)(p + 4 * lane); o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3]; }
         o.b = *(const xd_f2 *)(sA + dc * 256 + boff);
     };
-    auto fma = [&](auto dd, auto mm0, const XdOps &o, auto &&hook) __attribute__((always_inline)) {
+    auto fma = [&](auto dd, auto mm0, auto ff, const XdOps &o, auto &&hook) __attribute__((always_inline)) {
         constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc), M0 = decltype(mm0)::value;
+        constexpr bool FIRST = decltype(ff)::value;                         // the first stage of a class pass starts every chain from C = 0
         static_for<T>([&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, acc[tb + t][0]);
+            acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, FIRST ? zero4 : acc[tb + t][0]);
             hook(IC<M0 + 2 * t>{});
-            acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, acc[tb + t][1]);
+            acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, FIRST ? zero4 : acc[tb + t][1]);
             hook(IC<M0 + 2 * t + 1>{});
         });
     };
     unsigned stage = 0;
     auto stage_image = [&](unsigned par) __attribute__((always_inline)) { return ring + (par & 1u) * XQ_IMG; };
-    auto body = [&](auto NN, xd_gptr xk1, xd_gptr wk1, int cn1, unsigned voff1) __attribute__((always_inline)) {
+    auto body = [&](auto NN, auto ff, xd_gptr xk1, xd_gptr wk1, int cn1, unsigned voff1) __attribute__((always_inline)) {
         constexpr int N = decltype(NN)::value, NM = 2 * xd_tbase(N);
+        constexpr bool FIRST = decltype(ff)::value;
+        if constexpr (FIRST && N < XD_ND) {                                 // the tiles of the diagonals this body does not walk
+#pragma unroll
+            for (int i = xd_tbase(N); i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
+        }
         const float *sA = stage_image(stage);
         const unsigned dst = xd_lds_addr(stage_image(stage + 1));
         auto hook = [&](auto mm) __attribute__((always_inline)) {
@@ -840,7 +866,7 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
             constexpr int m0 = [] { int m = 0; for (int j = 0; j < i; ++j) m += 2 * xd_ntiles(xd_walk(N, j)); return m; }();
             if constexpr (i + XQ_PF < N) load_ops(IC<xd_walk(N, i + XQ_PF)>{}, ops[(i + XQ_PF) % (XQ_PF + 1)], sA);
             __builtin_amdgcn_sched_barrier(0);
-            fma(IC<dc>{}, IC<m0>{}, ops[i % (XQ_PF + 1)], hook);
+            fma(IC<dc>{}, IC<m0>{}, ff, ops[i % (XQ_PF + 1)], hook);
             __builtin_amdgcn_sched_barrier(0);
         });
         constexpr int HOOKED = (NM + XQ_DSTRIDE - 1) / XQ_DSTRIDE;
@@ -871,8 +897,6 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
 #endif
         static_for<XQ_NCLS>([&](auto cc) {
             constexpr int CLS = decltype(cc)::value;
-#pragma unroll
-            for (int i = 0; i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
             XD_T(0);
             {
                 xd_gptr xk = cur.xs, wk = cur.ws + (unsigned)CLS * cls_bytes;
@@ -880,6 +904,7 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
                 int nKmax = cur.nKmax;
                 asm volatile("" : "+s"(nKmax));
                 int kb = 0, D = X;
+                asm volatile("" : "+s"(D));                                     // (uniform: the first block's body is chosen by a scalar branch)
                 // the stage after block kb of class CLS: block kb + 1; or block 0 of the next class; or of the next task's class 0 (none: itself)
                 auto next_stage = [&](xd_gptr &xk1, xd_gptr &wk1, int &cn1, unsigned &v1) __attribute__((always_inline)) {
                     const bool inner = kb + 1 < nKmax;
@@ -897,22 +922,30 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
                     cn1 = __builtin_amdgcn_readfirstlane(cn1);
                     asm volatile("" : "+s"(xk1), "+s"(wk1));
                 };
+                // the first block starts the chains (X >= 7: eleven live diagonals, or seven for group block 0 of a hidden layer)
+                {
+                    xd_gptr xk1, wk1; int cn1; unsigned v1;
+                    next_stage(xk1, wk1, cn1, v1);
+                    if (D >= 8) body(IC<XD_ND>{}, IC<true>{}, xk1, wk1, cn1, v1);
+                    else body(IC<7>{}, IC<true>{}, xk1, wk1, cn1, v1);      // (X >= 7 always: 4 + hidden + XD_C0 + tc0, hidden layers only reach X = 7 at group block 0; X = 6 (first-layer rule) runs one dead diagonal)
+                    xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4); ++kb; D -= 4;
+                }
                 for (; kb < nKmax && D >= 8; ++kb, D -= 4) {
                     xd_gptr xk1, wk1; int cn1; unsigned v1;
                     next_stage(xk1, wk1, cn1, v1);
-                    body(IC<XD_ND>{}, xk1, wk1, cn1, v1);
+                    body(IC<XD_ND>{}, IC<false>{}, xk1, wk1, cn1, v1);
                     xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4);
                 }
                 if (kb < nKmax && D >= 4) {
                     xd_gptr xk1, wk1; int cn1; unsigned v1;
                     next_stage(xk1, wk1, cn1, v1);
-                    body(IC<7>{}, xk1, wk1, cn1, v1);
+                    body(IC<7>{}, IC<false>{}, xk1, wk1, cn1, v1);
                     xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4); ++kb; D -= 4;
                 }
                 if (kb < nKmax) {
                     xd_gptr xk1, wk1; int cn1; unsigned v1;
                     next_stage(xk1, wk1, cn1, v1);
-                    body(IC<3>{}, xk1, wk1, cn1, v1);
+                    body(IC<3>{}, IC<false>{}, xk1, wk1, cn1, v1);
                 }
             }
             // ---- halo of the two row halves of a sample (span tasks), then realignment + the reference tree inside the class

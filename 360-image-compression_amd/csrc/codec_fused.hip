@@ -1248,6 +1248,10 @@ __global__ void k_test_tab8(const int *__restrict__ tables, const float *__restr
     const int *T = tables + (start + i) * 9;
     const bool coded = !mask || !(mask[start + i] < 0.5f);
     if (coded && ((T[1] | T[2] | T[3] | T[4] | T[5] | T[6] | T[7]) & ~0xffff)) atomicOr(&st->error, 64);   // inner entries must fit 16 bits
+    // dec_pack8's words carry "coded" as T[7] << 16 != 0 (k_dec_plane skips a symbol whose word 7 is zero): a coded symbol with all mass
+    // on symbol 7 (T[1..7] == 0) would be skipped and the stream would desynchronise silently.  The codec's own tables are strictly
+    // increasing (lic360_cdf_fixup), this hook's callers must be told.
+    if (coded && T[7] == 0) atomicOr(&st->error, 64);
     uint4 r = make_uint4(0u, 0u, 0u, 0u), r2 = r;
     if (coded) dec_pack8(T, r, r2);
     tab[2 * i] = r;

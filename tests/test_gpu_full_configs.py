@@ -5,6 +5,7 @@ build container (tests/golden/full_*.npz, oracle/gen_golden_full.py; 27 s / 109 
   cfg3  configs[2]  single 512x1024 ERP decode,  model-idx 3 --ssim   -> decode of the ORACLE's bytes == the symbols
   cfg5  configs[4]  1024x2048 ERP (48x128x256 latent), model-idx 7 --ssim -> both directions
   cfg4  configs[3]  is the batch form of cfg3: test_batch_of_cfg3_images checks 8 images per call (one GPU's share)
+  cfg2b / cfg3b  a second oracle-pinned image of cfg2 / cfg3 at a dense / sparse importance mask (both directions for cfg3b via the batch test)
 """
 import hashlib
 import os
@@ -26,7 +27,8 @@ def dev(a):
 def load(name):
     g = np.load(os.path.join(GOLD, "full_%s.npz" % name))
     G, H, W = int(g["G"]), int(g["H"]), int(g["W"])
-    code, mask, levels = latent(np.random.default_rng(int(g["latent_seed"])), G, H, W)
+    dens = (float(g["mean"]), float(g["spread"])) if "mean" in g.files else (0.5, 0.25)
+    code, mask, levels = latent(np.random.default_rng(int(g["latent_seed"])), G, H, W, *dens)
     # the fixtures hold digests of the inputs they were made from: a drifting generator fails here, not as a byte mismatch
     assert hashlib.sha256(code.tobytes()).hexdigest() == str(g["code_sha256"])
     assert hashlib.sha256(mask.tobytes()).hexdigest() == str(g["mask_sha256"])
@@ -44,7 +46,7 @@ def codecs(shape, layers, imp_layers, batch=1):
     return fc, ic
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg2b", "cfg5"])
 def test_full_size_encode_bytes_equal_oracle(name):
     g, shape, code, mask, levels, layers, imp_layers = load(name)
     fc, ic = codecs(shape, layers, imp_layers)
@@ -55,7 +57,7 @@ def test_full_size_encode_bytes_equal_oracle(name):
     assert imp == g["imp_bytes"].tobytes() and hashlib.sha256(imp).hexdigest() == str(g["imp_sha256"])
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg3b", "cfg5"])
 def test_full_size_decode_of_oracle_bytes(name):
     g, shape, code, mask, levels, layers, imp_layers = load(name)
     fc, ic = codecs(shape, layers, imp_layers)
@@ -70,15 +72,16 @@ def test_batch_of_cfg3_images():
     the round trip and by image 0 staying byte-identical inside a batch (images are independent: SURVEY.md §8e)."""
     g, shape, code, mask, levels, layers, imp_layers = load("cfg3")
     G, H, W = shape
-    codes, masks = [code], [mask]
-    for i in range(1, 8):
+    gb, _, code_b, mask_b, _, _, _ = load("cfg3b")                            # image 1: the second oracle-pinned image (sparse mask, same weights)
+    codes, masks = [code, code_b], [mask, mask_b]
+    for i in range(2, 8):
         c, m, _ = latent(np.random.default_rng(3000 + i), G, H, W)
         codes.append(c)
         masks.append(m)
     code8, mask8 = np.concatenate(codes, 0), np.concatenate(masks, 0)
     fc, _ = codecs(shape, layers, imp_layers, batch=8)
     streams = fc.encode(dev(code8), dev(mask8))
-    assert streams[0] == g["bytes"].tobytes()
+    assert streams[0] == g["bytes"].tobytes() and streams[1] == gb["bytes"].tobytes()
     assert np.array_equal(fc.decode(streams, dev(mask8)).cpu().numpy(), code8 * mask8)
 
 

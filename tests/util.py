@@ -27,10 +27,11 @@ def conv_params(rng, nb, nout, C, k=5, act=True):
     return w, b, a
 
 
-def latent(rng, G, H, W):
-    """code in {0..7} ~ round(N(3.5,1.2^2)); importance level L[h/2,w/2] in {0..G}; mask[g,y,x] = g < L."""
+def latent(rng, G, H, W, mean=0.5, spread=0.25):
+    """code in {0..7} ~ round(N(3.5,1.2^2)); importance level L[h/2,w/2] in {0..G} ~ round(G (mean + spread N(0,1))); mask[g,y,x] = g < L.
+    (mean / spread: the mask density; the defaults are the generator every committed digest was made with)"""
     code = np.clip(np.rint(rng.normal(3.5, 1.2, (1, G, H, W))), 0, 7).astype(np.float32)
-    L = np.clip(np.rint(G / 2 + G / 4 * rng.standard_normal((H // 2, W // 2))), 0, G).astype(np.int64)
+    L = np.clip(np.rint(G * mean + G * spread * rng.standard_normal((H // 2, W // 2))), 0, G).astype(np.int64)
     Lup = np.repeat(np.repeat(L, 2, 0), 2, 1)
     mask = (np.arange(G)[:, None, None] < Lup[None]).astype(np.float32)[None]
     return code, mask, L.astype(np.float32)[None, None]

@@ -113,6 +113,6 @@ def measure(batches=(1, 32), device=0):
 
 
 if __name__ == "__main__":
-    rows = measure()
+    rows = measure(batches=tuple(int(b) for b in os.environ.get("SOB_BATCHES", "1,32").split(",")))
     print(json.dumps({"peak_GBps": PEAK, "note": "torch.cuda.Event timing of 50 back-to-back calls through the lic360 shim (includes its per-call Python/ctypes "
                   "overhead; single-image tensors are a few MB, so those rows are launch-latency bound)", "rows": rows}, indent=1))
