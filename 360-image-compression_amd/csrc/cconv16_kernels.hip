@@ -53,6 +53,7 @@
 #define C16_COMB (C16_TH * 4 * 4 * 64)     // tile rows x classes x registers x lanes
 #define C16_TPT 4                          // tiles per task
 #define C16_NBUF 3                         // LDS step buffers: the DMAs run two steps ahead of the MFMAs
+#define C16_FGPB 5                         // groups per block of the FUSED last layer (cout = 3: row = 3 q + r)
 
 static inline bool conv16_ok(const lic360_conv_plan *p) {
     return p->ksz == 5 && (p->cin == 1 || p->cin == 4) && p->cout >= 1 && p->cout <= 4 && p->ngroup >= 1 && p->ngroup <= 256;
@@ -67,8 +68,10 @@ static inline int conv16_ngb(const lic360_conv_plan *p) { return (p->ngroup + 3)
 //   cin = 4: slot = tap, gid = (c - tap) mod 4, input channel (tc0 + k) * 4 + gid;
 //   cin = 1: slot = 7 sq + j, tap = c + 4 j, input channel tc0 + 4 sq + k.
 // Zero where the chain has ended (tc >= L = g + 4 + hidden - kh - kw, capped at ngroup), for r >= cout, g >= ngroup, unused slots.
-__global__ void k_conv16_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int G, int cin, int cout, int hidden, int NS) {
-    const int n_gb = (G + 3) / 4, tcs = cin == 4 ? 4 : 16;
+// FUSED last layer (cout = 3, lic360_conv16_pack_tables): FIVE groups per block, row i = 3 q + r (15 of the 16 MFMA rows carry an output instead
+// of 12: 10 group blocks instead of 12 for 48 groups).
+__global__ void k_conv16_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int G, int cin, int cout, int hidden, int NS, int gpb, int rpg) {
+    const int n_gb = (G + gpb - 1) / gpb, tcs = cin == 4 ? 4 : 16;
     const long per_net = (long)n_gb * NS * C16_WFL, total = per_net * nb;
     const int C = G * cin, nout = G * cout;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -78,12 +81,12 @@ __global__ void k_conv16_pack(const float *__restrict__ weight, float *__restric
         const int c = (int)(t & 3); t >>= 2;
         const int step = (int)(t % NS); t /= NS;
         const int gb = (int)(t % n_gb), b = (int)(t / n_gb);
-        const int i = l & 15, k = l >> 4, q = i >> 2, r = i & 3, g = gb * 4 + q;
+        const int i = l & 15, k = l >> 4, q = i / rpg, r = i - q * rpg, g = gb * gpb + q;
         int tap, tc, ci;
         if (cin == 4) { tap = slot; tc = step * tcs + k; ci = tc * 4 + ((c - tap) & 3); }
         else { const int sq = slot / 7, j = slot % 7; tap = c + 4 * j; tc = step * tcs + 4 * sq + k; ci = tc; }
         float v = 0.0f;
-        if (tap < 25 && slot < (cin == 4 ? 25 : 28) && g < G && r < cout) {
+        if (tap < 25 && slot < (cin == 4 ? 25 : 28) && q < gpb && g < G && r < cout) {
             const int kh = tap / 5, kw = tap % 5;
             int L = g + 4 - kh - kw + hidden;                               // extension/cconv_ec_cuda.cu:288-290
             if (L > G) L = G;
@@ -101,7 +104,16 @@ LIC360_API int lic360_conv16_pack(void *stream, const lic360_conv_plan *p, const
     ARG_CHECK(p && conv16_ok(p) && weight && packed && nb > 0);
     const long total = lic360_conv16_packed_floats(p) * nb;
     hipLaunchKernelGGL(k_conv16_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, nb, p->ngroup, p->cin,
-                       p->cout, p->constrain == 5 ? 0 : 1, conv16_nsteps_max(p));
+                       p->cout, p->constrain == 5 ? 0 : 1, conv16_nsteps_max(p), 4, 4);
+    LAUNCH_CHECK();
+    return 0;
+}
+// the packing lic360_cconv16_ec_tables reads (cin = 4, cout = 3: five groups per block); fits the lic360_conv16_packed_floats allocation
+LIC360_API int lic360_conv16_pack_tables(void *stream, const lic360_conv_plan *p, const float *weight, int nb, float *packed) {
+    ARG_CHECK(p && conv16_ok(p) && p->cin == 4 && p->cout == 3 && weight && packed && nb > 0);
+    const long total = (long)((p->ngroup + C16_FGPB - 1) / C16_FGPB) * conv16_nsteps_max(p) * C16_WFL * nb;
+    hipLaunchKernelGGL(k_conv16_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, nb, p->ngroup, p->cin,
+                       p->cout, p->constrain == 5 ? 0 : 1, conv16_nsteps_max(p), C16_FGPB, 3);
     LAUNCH_CHECK();
     return 0;
 }
@@ -199,6 +211,7 @@ template <int CIN, int CLS, int PS, bool FUSE>
 __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *comb, int *tq, const int tid, const int lane) {
     static_assert(!FUSE || CIN == 4, "the fused table build belongs to the last (cin = 4) layer");
     constexpr int NSUB = FUSE ? 3 : 1;                                      // FUSE: the 3 stacked nets of an image, one after the other per tile
+    constexpr int GPB = FUSE ? C16_FGPB : 4, RPG = FUSE ? 3 : 4;            // groups per block, MFMA rows per group (row = RPG q + r)
     constexpr int NA = NAcc<CIN>::value;
     constexpr int TCS = CIN == 4 ? 4 : 16;                                  // input groups per step
     constexpr int WAVE = PS * 4 + CLS;
@@ -222,7 +235,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         n = xcd + 8 * (v / a.n_chunks);
     };
     auto steps_of = [&](int gb) __attribute__((always_inline)) {
-        int gl = gb * 4 + 3;
+        int gl = gb * GPB + GPB - 1;
         if (gl > G - 1) gl = G - 1;
         int L = gl + 4 + a.hidden;
         if (L > G) L = G;
@@ -342,9 +355,9 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         // (softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159) and writes the symbol's
         // (cdf[sym], cdf[sym+1]) record at its place in coding order (tile_extract_cuda.cu:36-41)
         __syncthreads();
-        if (tid < 256) {
+        if (tid < 64 * GPB) {
             const int ty = tb_T / a.ntx, tx = tb_T - ty * a.ntx;
-            const int q = tid >> 6, pos = tid & 63, th = ty * C16_TH + (pos >> 4), tw = tx * C16_TW + (pos & 15), g = tb_gb * 4 + q;
+            const int q = tid >> 6, pos = tid & 63, th = ty * C16_TH + (pos >> 4), tw = tx * C16_TW + (pos & 15), g = tb_gb * GPB + q;
             if (g < G && th < a.H && tw < a.W) {
                 const long HW = (long)a.H * a.W, i = (((long)tb_n * G + g) * a.H + th) * a.W + tw;
                 const int sd = th + tw, p = sd + g, la = p >= G ? p - G + 1 : 0;
@@ -355,7 +368,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
 #pragma unroll
                     for (int net = 0; net < 3; ++net)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + ((net * 4 + q) * 3 + c) * 64 + pos];
+                        for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + ((net * GPB + q) * 3 + c) * 64 + pos];
                     int Tb[9];
                     gmm_cdf9(v, v + 3, v + 6, Tb);
                     int sym = (int)a.code[i];
@@ -375,7 +388,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         const float *xs = lds + cur * C16_BUF + xlane, *ws = lds + cur * C16_BUF + wlane;
         const int nbuf = cur >= 1 ? cur - 1 : C16_NBUF - 1;                  // DMAs of the step after next go to (cur + 2) mod 3
         if constexpr (CIN == 1) issue(nbuf);
-        const int g0 = c_gb * 4, dl = g0 + 7 + a.hidden - cstep * TCS;      // tap diagonals d >= dl carry only zero weights
+        const int g0 = c_gb * GPB, dl = g0 + GPB + 3 + a.hidden - cstep * TCS;   // tap diagonals d >= dl carry only zero weights (the block's last group has the longest chains)
         // bias / PReLU slope / residual of the tile are fetched at the START of its last step, from clamped addresses (they
         // are the oldest loads in flight when the epilogue needs them: waiting for them there stalled all eight waves for
         // three dependent memory round trips per tile, ~25 % of the kernel)
@@ -388,12 +401,18 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
             const int gc = g < G ? g : G - 1;
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * (WAVE & 1) + rr, rc = r < a.cout ? r : a.cout - 1;
-                const int o = gc * a.cout + rc, bid = (FUSE ? cnet : c_n / a.npb) * nout + o;
-                e_oi[rr] = ((long)c_n * nout + o) * PL + (long)((y < a.H ? y : a.H - 1) + 2) * a.wp + (x < a.W ? x : a.W - 1) + 2;
-                e_bias[rr] = a.bias[bid];
-                e_act[rr] = act_p[bid];
-                e_res[rr] = res_p[a.residual ? e_oi[rr] : 0];
+                const int r = 2 * (WAVE & 1) + rr;
+                if constexpr (FUSE) {                                       // MFMA row m = 4 q + r = 3 (group in block) + channel
+                    const int m = 4 * q + r, gq = m / 3, ch = m - 3 * gq, gg = c_gb * GPB + gq;
+                    e_bias[rr] = a.bias[cnet * nout + (gg < G ? gg : G - 1) * 3 + ch];
+                } else {
+                    const int rc = r < a.cout ? r : a.cout - 1;
+                    const int o = gc * a.cout + rc, bid = (c_n / a.npb) * nout + o;
+                    e_oi[rr] = ((long)c_n * nout + o) * PL + (long)((y < a.H ? y : a.H - 1) + 2) * a.wp + (x < a.W ? x : a.W - 1) + 2;
+                    e_bias[rr] = a.bias[bid];
+                    e_act[rr] = act_p[bid];
+                    e_res[rr] = res_p[a.residual ? e_oi[rr] : 0];
+                }
             }
         }
         if constexpr (CIN == 4) {
@@ -483,8 +502,9 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 float sv = ((f0 + f2) + (f1 + f3)) + e_bias[rr];
                 if (a.act) sv = sv > 0 ? sv : sv * e_act[rr];                // cconv_ec_cuda.cu:311-312
                 if (a.residual) sv = sv + e_res[rr];
-                if constexpr (FUSE) {                                       // y of (net, group q, channel r) at tile position (trow, j)
-                    if (r < 3) comb[C16_COMB + ((cnet * 4 + (lane >> 4)) * 3 + r) * 64 + trow * 16 + (lane & 15)] = sv;
+                if constexpr (FUSE) {                                       // y of (net, group gq, channel ch) at tile position (trow, j): MFMA row m = 3 gq + ch
+                    const int m = 4 * (lane >> 4) + r, gq = m / 3, ch = m - 3 * gq;
+                    if (m < 3 * GPB) comb[C16_COMB + ((cnet * GPB + gq) * 3 + ch) * 64 + trow * 16 + (lane & 15)] = sv;
                 } else if (e_ok && r < a.cout) a.out[e_oi[rr]] = sv;
             }
             if constexpr (FUSE) {
@@ -579,6 +599,7 @@ LIC360_API int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *p,
     a.x = x; a.packed = packed16; a.bias = bias; a.act = nullptr; a.residual = nullptr; a.out = nullptr; a.ctr = ctr;
     a.npb = images; a.x_mod = 3 * images; a.N = images;
     if (c16_fill_args(a, p, h, w)) return 2;
+    a.n_gb = (p->ngroup + C16_FGPB - 1) / C16_FGPB;                         // five groups per block (lic360_conv16_pack_tables)
     a.code = code; a.mask = mask; a.pidx = pidx_dev; a.plane_start = plane_start_dev; a.rec = (uint2 *)rec;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));

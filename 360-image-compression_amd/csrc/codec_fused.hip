@@ -702,7 +702,9 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
     }
     if (lic360_conv_pack(stream, p, weight, 3, c->packed[layer])) return 1;
     if (c->use4 && lic360_conv4_pack(stream, p, weight, 3, c->packed4[layer])) return 1;
-    if (c->use16 && lic360_conv16_pack(stream, p, weight, 3, c->packed16[layer])) return 1;
+    // (the fused last layer + CDF tables reads a packing of its own: five groups per block)
+    if (c->use16 && ((layer == 11 && c->fuse_tables) ? lic360_conv16_pack_tables(stream, p, weight, 3, c->packed16[layer])
+                                                      : lic360_conv16_pack(stream, p, weight, 3, c->packed16[layer]))) return 1;
     if (c->use16dc && layer >= 1 && lic360_conv16dc_pack(stream, p, weight, 3, c->packed16dc[layer])) return 1;
     HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -198,6 +198,9 @@ int lic360_ec16_layout(int h, int w, int *hp, int *wp);
 int lic360_conv16_supported(const lic360_conv_plan *plan);
 long lic360_conv16_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv16_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16);
+/* the weight layout lic360_cconv16_ec_tables reads (cin = 4, cout = 3): five groups per block, MFMA row = 3 (group in block) + channel,
+ * so that 15 of 16 MFMA rows carry an output; fits a lic360_conv16_packed_floats allocation */
+int lic360_conv16_pack_tables(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16);
 int lic360_cconv16_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr);
 
@@ -223,7 +226,8 @@ int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *plan, const fl
  * test/lic360_demo.py:132-140, extension/entropy_gmm_table_cuda.cu:138-191): x = activations of the three stacked nets
  * [weight, sigma, mu], [3*images][C][hp][wp] net-major in the lic360_ec16_layout; code / mask [images, G, h, w]; pidx_dev /
  * plane_start_dev = device copies of CodeContex's prefix table [h+w] and of the index of each plane's first record
- * [h+w+G-1]; rec = uint32 pairs [images][G*h*w] (cdf[sym], cdf[sym+1]) in coding order, (0,0) where masked. */
+ * [h+w+G-1]; rec = uint32 pairs [images][G*h*w] (cdf[sym], cdf[sym+1]) in coding order, (0,0) where masked.
+ * packed16: from lic360_conv16_pack_tables (NOT lic360_conv16_pack). */
 int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
                              const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
                              void *rec, int images, int h, int w, int *ctr);

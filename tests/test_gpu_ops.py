@@ -994,7 +994,7 @@ def test_cconv16_last_layer_with_fused_tables(lic, G, B, H, W):
     rec = torch.full((B, G * H * W, 2), -1, dtype=torch.int32, device="cuda:0")
     ctr = torch.zeros(8, dtype=torch.int32, device="cuda:0")
     s, Pp = lic._stream(0), lic._p
-    assert L.lic360_conv16_pack(s, plan, Pp(wd), 3, Pp(packed)) == 0
+    assert L.lic360_conv16_pack_tables(s, plan, Pp(wd), 3, Pp(packed)) == 0
     assert L.lic360_cconv16_ec_tables(s, plan, Pp(xd), Pp(packed), Pp(bd), Pp(cd), Pp(md), Pp(pd), Pp(psd), Pp(rec), B, H, W, Pp(ctr)) == 0, L.lic360_last_error()
     got = host(rec).astype(np.int64).astype(np.uint32)
     L.lic360_conv_plan_destroy(plan)
