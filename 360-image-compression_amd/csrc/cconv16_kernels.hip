@@ -54,6 +54,8 @@
 #define C16_TPT 4                          // tiles per task
 #define C16_NBUF 3                         // LDS step buffers: the DMAs run two steps ahead of the MFMAs
 #define C16_FGPB 5                         // groups per block of the FUSED last layer (cout = 3: row = 3 q + r)
+#define C16_FTPT 2                         // tiles per task of the FUSED last layer: its three nets run as PHASES over them (y parked in LDS)
+#define C16_YFL (C16_FTPT * 3 * C16_FGPB * 3 * 64)   // floats of the parked y: [tile][net][group][channel][position]
 
 static inline bool conv16_ok(const lic360_conv_plan *p) {
     return p->ksz == 5 && (p->cin == 1 || p->cin == 4) && p->cout >= 1 && p->cout <= 4 && p->ngroup >= 1 && p->ngroup <= 256;
@@ -212,6 +214,11 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     static_assert(!FUSE || CIN == 4, "the fused table build belongs to the last (cin = 4) layer");
     constexpr int NSUB = FUSE ? 3 : 1;                                      // FUSE: the 3 stacked nets of an image, one after the other per tile
     constexpr int GPB = FUSE ? C16_FGPB : 4, RPG = FUSE ? 3 : 4;            // groups per block, MFMA rows per group (row = RPG q + r)
+    // tiles per task.  FUSE: the task's tiles are swept once per net (net 0 over all of them, then net 1, then net 2), so that the
+    // workgroups of an XCD -- which start together and run equal task shapes -- stream ONE net's weights at a time (cycling the nets per
+    // tile tripled the weight working set: 33 GB of fabric traffic per launch for 1.2 GB of algorithmic bytes); the nets' outputs wait
+    // in LDS for the table phase
+    constexpr int TPT = FUSE ? C16_FTPT : C16_TPT;
     constexpr int NA = NAcc<CIN>::value;
     constexpr int TCS = CIN == 4 ? 4 : 16;                                  // input groups per step
     constexpr int WAVE = PS * 4 + CLS;
@@ -231,7 +238,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         const int left = units - blk * a.gbk, kk = left < a.gbk ? left : a.gbk;
         gb = a.n_gb - 1 - r / kk;
         const int v = blk * a.gbk + r % kk;
-        tile0 = (v % a.n_chunks) * C16_TPT;
+        tile0 = (v % a.n_chunks) * TPT;
         n = xcd + 8 * (v / a.n_chunks);
     };
     auto steps_of = [&](int gb) __attribute__((always_inline)) {
@@ -302,17 +309,26 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         if (ivalid) {
             if (++istep == i_nsteps) {
                 istep = 0;
-                if (++inet == NSUB) {
-                    inet = 0;
+                if constexpr (FUSE) {                                       // tile fastest, then net, then the next task
                     ++itile;
-                    if (itile == C16_TPT || i_tile0 + itile >= a.ntiles) {
+                    if (itile == TPT || i_tile0 + itile >= a.ntiles) {
+                        itile = 0;
+                        if (++inet == NSUB) {
+                            inet = 0;
+                            ++iq;
+                            issue_task();
+                        }
+                    }
+                } else {
+                    ++itile;
+                    if (itile == TPT || i_tile0 + itile >= a.ntiles) {
                         itile = 0;
                         ++iq;
                         issue_task();
                     }
                 }
                 if (ivalid) issue_tile();
-                else { istep = i_nsteps - 1; inet = NSUB - 1; }               // idle: stay on the last step
+                else { istep = i_nsteps - 1; inet = NSUB - 1; itile = 0; }     // idle: stay on the last step
             }
         }
     };
@@ -349,35 +365,59 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     // FUSE: table build of a finished tile.  It runs at the top of the NEXT tile's first step -- where every accumulator is dead
     // (the first step starts all chains from C = 0), so its ~90 registers do not compete with them -- or after the loop.
     bool tb_pending = false;
-    int tb_T = 0, tb_n = 0, tb_gb = 0;
+    int tb_T = 0, tb_nt = 0, tb_n = 0, tb_gb = 0;                           // first tile and tile count of the finished task
     auto tables = [&]() __attribute__((always_inline)) {
-        // all three nets of the tile are in LDS: one thread per symbol (4 groups x 64 positions) builds the 9-entry CDF
-        // (softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159) and writes the symbol's
-        // (cdf[sym], cdf[sym+1]) record at its place in coding order (tile_extract_cuda.cu:36-41)
+        // all three nets of the task's tiles are in LDS: a thread per coded symbol builds the 9-entry CDF (softmax, sigma floor, erf CDF,
+        // fix-up: entropy_gmm_table_cuda.cu:29-107,138-159) and writes the symbol's (cdf[sym], cdf[sym+1]) record at its place in coding order
+        // Two passes over the task's (tile, group, position) symbols: masked ones get their (0, 0) record at once, the coded ones are
+        // COMPACTED into a list first (the partial-sum half of comb is dead here), so that the CDF arithmetic -- 9 % of the kernel when
+        // every thread that owned a symbol ran it, masked or not, in lockstep with its wave -- runs on dense waves.
+        int *const tl = (int *)comb;                                        // [0, 64 GPB TPT): item list, then the counter
+        int *const tcnt = tl + 64 * GPB * TPT;
+        __syncthreads();                                                    // the last tile's y is complete, its partial sums have been read
+        if (tid == 0) *tcnt = 0;
         __syncthreads();
-        if (tid < 64 * GPB) {
-            const int ty = tb_T / a.ntx, tx = tb_T - ty * a.ntx;
-            const int q = tid >> 6, pos = tid & 63, th = ty * C16_TH + (pos >> 4), tw = tx * C16_TW + (pos & 15), g = tb_gb * GPB + q;
+        const long HW = (long)a.H * a.W;
+        auto locate = [&](int item, int &g, int &th, int &tw, int &pos, int &tt, int &q) __attribute__((always_inline)) {
+            tt = item / (64 * GPB);
+            const int w = item - tt * (64 * GPB);
+            q = w >> 6; pos = w & 63;
+            const int T = tb_T + tt, ty = T / a.ntx, tx = T - ty * a.ntx;
+            th = ty * C16_TH + (pos >> 4); tw = tx * C16_TW + (pos & 15); g = tb_gb * GPB + q;
+        };
+        auto record_at = [&](int g, int th, int tw) __attribute__((always_inline)) -> long {      // the symbol's place in coding order (tile_extract_cuda.cu:36-41)
+            const int sd = th + tw, p = sd + g, la = p >= G ? p - G + 1 : 0;
+            return (long)tb_n * G * HW + a.plane_start[p] + (a.pidx[sd] - a.pidx[la]) + (th - (sd >= a.W ? sd - a.W + 1 : 0));
+        };
+        for (int item = tid; item < tb_nt * 64 * GPB; item += C16_THREADS) {
+            int g, th, tw, pos, tt, q;
+            locate(item, g, th, tw, pos, tt, q);
             if (g < G && th < a.H && tw < a.W) {
-                const long HW = (long)a.H * a.W, i = (((long)tb_n * G + g) * a.H + th) * a.W + tw;
-                const int sd = th + tw, p = sd + g, la = p >= G ? p - G + 1 : 0;
-                const long k = a.plane_start[p] + (a.pidx[sd] - a.pidx[la]) + (th - (sd >= a.W ? sd - a.W + 1 : 0));
-                uint2 rv = make_uint2(0u, 0u);
-                if (!(a.mask[i] < 0.5f)) {                                   // coder.cpp:79
-                    float v[9];
-#pragma unroll
-                    for (int net = 0; net < 3; ++net)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + ((net * GPB + q) * 3 + c) * 64 + pos];
-                    int Tb[9];
-                    gmm_cdf9(v, v + 3, v + 6, Tb);
-                    int sym = (int)a.code[i];
-                    sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
-                    rv = make_uint2((unsigned)Tb[sym], (unsigned)Tb[sym + 1]);
-                }
-                a.rec[(long)tb_n * G * HW + k] = rv;
+                if (a.mask[(((long)tb_n * G + g) * a.H + th) * a.W + tw] < 0.5f) a.rec[record_at(g, th, tw)] = make_uint2(0u, 0u);   // coder.cpp:79
+                else tl[atomicAdd(tcnt, 1)] = item;
             }
         }
+        __syncthreads();
+        const int ncoded = *tcnt;
+        for (int t = tid; t < ncoded; t += C16_THREADS) {
+            int g, th, tw, pos, tt, q;
+            locate(tl[t], g, th, tw, pos, tt, q);
+            float v[9];
+#pragma unroll
+            for (int net = 0; net < 3; ++net)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + (((tt * 3 + net) * GPB + q) * 3 + c) * 64 + pos];
+            int Tb[9];
+#ifdef C16_EXP_NOTAB                                                          // ablation (timing only): what the CDF arithmetic of the table phase costs
+            for (int e = 0; e < 9; ++e) Tb[e] = (int)v[e];
+#else
+            gmm_cdf9(v, v + 3, v + 6, Tb);                                  // softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159
+#endif
+            int sym = (int)a.code[(((long)tb_n * G + g) * a.H + th) * a.W + tw];
+            sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
+            a.rec[record_at(g, th, tw)] = make_uint2((unsigned)Tb[sym], (unsigned)Tb[sym + 1]);
+        }
+        __syncthreads();                                                    // (the list lies where the next tile's partial sums go)
         tb_pending = false;
     };
     // (comb is double-buffered by tile parity: with one-step tiles the next tile's partial sums are written before the
@@ -504,22 +544,25 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 if (a.residual) sv = sv + e_res[rr];
                 if constexpr (FUSE) {                                       // y of (net, group gq, channel ch) at tile position (trow, j): MFMA row m = 3 gq + ch
                     const int m = 4 * (lane >> 4) + r, gq = m / 3, ch = m - 3 * gq;
-                    if (m < 3 * GPB) comb[C16_COMB + ((cnet * GPB + gq) * 3 + ch) * 64 + trow * 16 + (lane & 15)] = sv;
+                    if (m < 3 * GPB) comb[C16_COMB + (((ctile * 3 + cnet) * GPB + gq) * 3 + ch) * 64 + trow * 16 + (lane & 15)] = sv;
                 } else if (e_ok && r < a.cout) a.out[e_oi[rr]] = sv;
-            }
-            if constexpr (FUSE) {
-                if (cnet == NSUB - 1) { tb_pending = true; tb_T = c_tile0 + ctile; tb_n = c_n; tb_gb = c_gb; }
             }
             cstep = 0;
             ++ntile;
             if constexpr (FUSE) {
                 if (c_nsteps == 1) __syncthreads();                         // one-step tiles: the single comb buffer is rewritten before the next barrier
             }
-            if (++cnet < NSUB) { cur = cur + 1 == C16_NBUF ? 0 : cur + 1; continue; }   // FUSE: same tile, next net
-            cnet = 0;
             ++ctile;
-            if (ctile == C16_TPT || c_tile0 + ctile >= a.ntiles) {
-                ctile = 0;
+            bool task_done = ctile == TPT || c_tile0 + ctile >= a.ntiles;
+            if constexpr (FUSE) {
+                if (task_done) {                                            // this net's sweep over the task's tiles is complete
+                    const int nt = ctile;
+                    ctile = 0;
+                    if (++cnet < NSUB) task_done = false;                   // the same tiles, next net
+                    else { cnet = 0; tb_pending = true; tb_T = c_tile0; tb_nt = nt; tb_n = c_n; tb_gb = c_gb; }
+                }
+            } else if (task_done) ctile = 0;
+            if (task_done) {
                 ++cq;
                 pull(cq + 4);                                               // first read at least one barrier later
                 const int u = task(cq);
@@ -536,7 +579,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
 template <int CIN, bool FUSE>
 __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
     __shared__ float lds[C16_NBUF * C16_BUF];
-    __shared__ float comb[2 * C16_COMB];                                   // FUSE: [partial sums | y of the tile's three nets]
+    __shared__ float comb[FUSE ? (C16_COMB + C16_YFL) : 2 * C16_COMB];     // FUSE: [partial sums | y of the task's tiles x three nets]
     __shared__ int tq[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -555,13 +598,13 @@ __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
     }
 }
 
-static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w) {
+static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w, int tpt = C16_TPT) {
     a.G = p->ngroup; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w;
     if (lic360_ec16_layout(h, w, &a.hp, &a.wp)) return 2;
     a.n_gb = conv16_ngb(p);
     a.ntx = (w + C16_TW - 1) / C16_TW;
     a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
-    a.n_chunks = (a.ntiles + C16_TPT - 1) / C16_TPT;
+    a.n_chunks = (a.ntiles + tpt - 1) / tpt;
     a.NS = conv16_nsteps_max(p);
     { static const int k = getenv("LIC360_C16_K") ? atoi(getenv("LIC360_C16_K")) : 16; a.gbk = k > 0 ? k : 1; }
     a.code = a.mask = nullptr; a.pidx = a.plane_start = nullptr; a.rec = nullptr;
@@ -598,7 +641,7 @@ LIC360_API int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *p,
     C16Args a;
     a.x = x; a.packed = packed16; a.bias = bias; a.act = nullptr; a.residual = nullptr; a.out = nullptr; a.ctr = ctr;
     a.npb = images; a.x_mod = 3 * images; a.N = images;
-    if (c16_fill_args(a, p, h, w)) return 2;
+    if (c16_fill_args(a, p, h, w, C16_FTPT)) return 2;
     a.n_gb = (p->ngroup + C16_FGPB - 1) / C16_FGPB;                         // five groups per block (lic360_conv16_pack_tables)
     a.code = code; a.mask = mask; a.pidx = pidx_dev; a.plane_start = plane_start_dev; a.rec = (uint2 *)rec;
     hipStream_t s = (hipStream_t)stream;
