@@ -1109,7 +1109,8 @@ LIC360_API int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *p, 
     if (gb_hi < 0) return 0;
     a.gb_hi = gb_hi; a.n_gbv = gb_hi - gb_lo + 1;
     ARG_CHECK(a.n_gbv <= 32);
-    hipLaunchKernelGGL(k_cconv16dq, dim3(512), dim3(XQ_THREADS), 0, (hipStream_t)stream, a);
+    static const int grid = [] { const char *e = getenv("LIC360_DQ_GRID"); const int g = e ? atoi(e) : 0; return g >= 8 && g <= 2048 ? g : 512; }();   // (diagnostic: 256 = one workgroup per CU)
+    hipLaunchKernelGGL(k_cconv16dq, dim3(grid), dim3(XQ_THREADS), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return 0;
 }
