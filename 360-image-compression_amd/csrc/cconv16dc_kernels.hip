@@ -707,10 +707,10 @@ LIC360_API int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *p, 
 #endif
 
 template <int WV>
-__device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *halo, float *hs_all, const int lane) {
+__device__ __forceinline__ void xq_body(const XdArgs &a, float *ringA, float *ringB, float *halo, float *hs_all, const int lane) {
     float *const hs = hs_all + WV * (XD_GB * 2 * 2 * 64) + lane;            // this lane's class partials [group][output row][class parity] (LDS: 12 registers too many)
     constexpr int PAIR = WV >> 1, HALF = WV & 1;                            // wave = (sample slot pair, row half)
-    constexpr int NA_DMA = WV < 2 ? 2 : 1, NB_DMA = HALF ? XD_ND - 6 : 6, NDMA = NA_DMA + NB_DMA;   // this wave's share of a stage's 28 DMAs
+    constexpr int NA_DMA = WV < 2 ? 2 : 1;                                  // this wave's share of a stage's six weight chunks (chunk WV + 4 j)
     const int G = a.G, H = a.H, W = a.W, S = H + W - 1, C = G * 4, nout = G * a.cout, HP = a.HP;
     const long SKP = a.SKP;
     const int n16 = lane & 15, kl = lane >> 4;
@@ -750,9 +750,8 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
 #endif
     struct Task {
         int tc0, s0, n_w, net, pbase, X, nKmax, gb;
-        unsigned d0, d1;
         bool span, valid_w;
-        xd_gptr xs, ws;                                                     // ws: packed weights of (net, group block), class 0
+        xd_gptr xs, ws;                                                     // xs: this wave's sample; ws: packed weights of (net, group block), class 0
     };
     int scan_j = 0, scan_base = 0;
     auto decode = [&](int kt, Task &t) __attribute__((always_inline)) {
@@ -789,109 +788,153 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
         t.pbase = T0 + (t.span ? 32 * HALF : 0);
         t.X = t.tc0 + 4 + a.hidden + XD_C0;
         t.nKmax = ((t.X < G ? t.X : G) + 3) >> 2;
-        const int iA = nA < a.x_mod ? nA : nA % a.x_mod, iB = nB < a.x_mod ? nB : nB % a.x_mod, i0 = iA < iB ? iA : iB;
-        const long sample_bytes = (long)C * SKP * 4;
-        t.d0 = (unsigned)((iA - i0) * sample_bytes); t.d1 = (unsigned)((iB - i0) * sample_bytes);
-        t.xs = (xd_gptr)(a.x + (long)i0 * C * SKP + (long)t.s0 * HP + XD_COL0);
+        const int iw = t.n_w < a.x_mod ? t.n_w : t.n_w % a.x_mod;
+        t.xs = (xd_gptr)(a.x + (long)iw * C * SKP + (long)t.s0 * HP + XD_COL0);
         t.ws = (xd_gptr)(a.packed + (((long)net * a.ngb_all + gb) * 4 * a.NKB) * XD_STAGE_A);
         return true;
     };
     const unsigned lane16 = (unsigned)lane * 16u;
-    auto dma_lane_offset = [&](const Task &t) __attribute__((always_inline)) -> unsigned {        // as in xd_body: the pair's 64 rows of one diagonal
-        const int h = (lane >> 4) & 1, k = 2 * (lane >> 5) + ((lane >> 3) & 1), m = lane & 7;
-        int r = (t.span ? 32 * h : t.pbase) + 4 * m;
-        if (r >= H + 2) r = H - 2 > 0 ? H - 2 : 0;
-        return (unsigned)((4 * k * (int)SKP + r) * 4) + (h ? t.d1 : t.d0);
+    // ---- staging (round 4, second form).  WEIGHTS: one 6 KB image per stage, shared by the workgroup, double-buffered, fetched one
+    // stage ahead (they come from L2), published by the stage barrier.  ACTIVATIONS: every wave fetches ITS OWN 32 rows into a PRIVATE
+    // ring of two stages -- unit u of a stage = the two diagonals (5 + u, 4 - u) of the walk 5, 4, 6, 3, ... (1 KB: lanes 0..31 the first,
+    // lanes 32..63 the second diagonal; 4 channel planes x 8 row quads each) -- and refills a unit's slot right after its MFMAs with the
+    // unit of the stage AFTER NEXT.  Nothing but the wave's own vmcnt orders those reads, so the activations -- which come from beyond L2
+    // -- have two full stages to land and no barrier waits for them (with both operands one stage ahead in a shared image a wave waited
+    // 18 % of its time for its own DMAs and 7 % at stage barriers behind the others').
+    constexpr int NU = 6;                                                   // units per stage
+    float *const bring = ringB + WV * (2 * NU * 256);
+    const unsigned bring_lds = xd_lds_addr(bring);
+    auto dma_lane_offset = [&](const Task &t) __attribute__((always_inline)) -> unsigned {        // lane l = 32 w + 8 k + m: rows pbase + 4 m .. + 3 of plane k
+        const int k = (lane >> 3) & 3, m = lane & 7;
+        int r = t.pbase + 4 * m;
+        if (r >= H + 2) r = H - 2 > 0 ? H - 2 : 0;                           // stay inside the sample's planes (rows behind the image reach no stored output)
+        return (unsigned)((4 * k * (int)SKP + r) * 4);
     };
     const unsigned hp4 = (unsigned)HP * 4u, skp4 = (unsigned)SKP * 4u, kbx = 16u * skp4;
     const unsigned cls_bytes = (unsigned)a.NKB * (XD_STAGE_A * 4);          // packed weights of one class of a (net, group block)
-    // DMA j of this wave for the stage (class cn, weights at wk, activations at xk): j < NA_DMA: weight chunk WV + 4 j; else the pair's
-    // diagonal 6 HALF + j - NA_DMA
-    auto dma_one = [&](auto jj, xd_gptr xk, xd_gptr wk, int cn, unsigned voff, unsigned dst) __attribute__((always_inline)) {
-        constexpr int j = decltype(jj)::value;
-        if constexpr (j < NA_DMA) {
-            constexpr unsigned ch = (unsigned)(WV + 4 * j) * 1024u;
-            xd_dma(lane16, wk + ch, dst + ch);
-        } else {
-            constexpr int dc = 6 * HALF + (j - NA_DMA);
-            const unsigned gid = (unsigned)(cn + XD_C0 + 16 - dc) & 3u;
-            xd_dma(voff, xk + ((unsigned)dc * hp4 + gid * skp4), dst + (unsigned)(XD_STAGE_A + (PAIR * XD_ND + dc) * 256) * 4u);
-        }
-    };
-    const int boff = XD_STAGE_A + PAIR * XD_ND * 256 + 4 * (32 * (kl >> 1) + 16 * HALF + 8 * (kl & 1) + (n16 >> 1)) + 2 * (n16 & 1);
+    // a stage = (task: 0 current / 1 next, class, K block)
+    struct Stage { int sel, cls, kb; };
+    // ---- MFMA-side operand addresses
+    const int boffA = 4 * (8 * kl + (n16 >> 1)) + 2 * (n16 & 1), boffB = boffA + 128;   // floats inside a unit's slot: first / second diagonal
     f32x4 acc[XD_NT][2];
-    auto load_ops = [&](auto dd, XdOps &o, const float *sA) __attribute__((always_inline)) {
+    struct Ops2 { float a[7]; xd_f2 ba, bb; };                              // weights of the unit's two diagonals (<= 4 + 3 tiles), its two B operands
+    constexpr auto unit_da = [](int u) { return 5 + u; };
+    constexpr auto unit_db = [](int u) { return u < 5 ? 4 - u : -1; };
+    auto load_a = [&](auto dd, float *o, const float *sA) __attribute__((always_inline)) {
         constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
         const float *p = sA + tb * 64;
-        if constexpr (T == 1) o.a[0] = p[lane];
-        else if constexpr (T == 2) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; }
-        else if constexpr (T == 3) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; o.a[2] = p[128 + lane]; }
-        else { const f32x4 v = *(const f32x4 *)(p + 4 * lane); o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3]; }
-        o.b = *(const xd_f2 *)(sA + dc * 256 + boff);
+        if constexpr (T == 1) o[0] = p[lane];
+        else if constexpr (T == 2) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o[0] = v.x; o[1] = v.y; }
+        else if constexpr (T == 3) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o[0] = v.x; o[1] = v.y; o[2] = p[128 + lane]; }
+        else { const f32x4 v = *(const f32x4 *)(p + 4 * lane); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
     };
-    auto fma = [&](auto dd, auto mm0, auto ff, const XdOps &o, auto &&hook) __attribute__((always_inline)) {
-        constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc), M0 = decltype(mm0)::value;
+    // operands of unit U of a body with N live diagonals: weights from the shared image sA, activations from this wave's ring slot
+    auto load_unit = [&](auto NN, auto uu, Ops2 &o, const float *sA, const float *slot) __attribute__((always_inline)) {
+        constexpr int N = decltype(NN)::value, U = decltype(uu)::value, DA = unit_da(U), DB = unit_db(U);
+        if constexpr (DA < N) { load_a(IC<DA>{}, o.a, sA); o.ba = *(const xd_f2 *)(slot + boffA); }
+        if constexpr (DB >= 0 && DB < N) { load_a(IC<(DB >= 0 ? DB : 0)>{}, o.a + (DA < N ? xd_ntiles(DA) : 0), sA); o.bb = *(const xd_f2 *)(slot + boffB); }
+    };
+    auto fma_d = [&](auto dd, auto ff, const float *w, const xd_f2 &b) __attribute__((always_inline)) {
+        constexpr int dc = decltype(dd)::value, T = xd_ntiles(dc), tb = xd_tbase(dc);
         constexpr bool FIRST = decltype(ff)::value;                         // the first stage of a class pass starts every chain from C = 0
         static_for<T>([&](auto tt) {
             constexpr int t = decltype(tt)::value;
-            acc[tb + t][0] = xd_mfma(o.a[t], o.b.x, FIRST ? zero4 : acc[tb + t][0]);
-            hook(IC<M0 + 2 * t>{});
-            acc[tb + t][1] = xd_mfma(o.a[t], o.b.y, FIRST ? zero4 : acc[tb + t][1]);
-            hook(IC<M0 + 2 * t + 1>{});
+            acc[tb + t][0] = xd_mfma(w[t], b.x, FIRST ? zero4 : acc[tb + t][0]);
+            acc[tb + t][1] = xd_mfma(w[t], b.y, FIRST ? zero4 : acc[tb + t][1]);
         });
     };
-    unsigned stage = 0;
-    auto stage_image = [&](unsigned par) __attribute__((always_inline)) { return ring + (par & 1u) * XQ_IMG; };
-    auto body = [&](auto NN, auto ff, xd_gptr xk1, xd_gptr wk1, int cn1, unsigned voff1) __attribute__((always_inline)) {
-        constexpr int N = decltype(NN)::value, NM = 2 * xd_tbase(N);
+    auto fma_unit = [&](auto NN, auto uu, auto ff, const Ops2 &o) __attribute__((always_inline)) {
+        constexpr int N = decltype(NN)::value, U = decltype(uu)::value, DA = unit_da(U), DB = unit_db(U);
+        if constexpr (DA < N) fma_d(IC<DA>{}, ff, o.a, o.ba);
+        if constexpr (DB >= 0 && DB < N) fma_d(IC<(DB >= 0 ? DB : 0)>{}, ff, o.a + (DA < N ? xd_ntiles(DA) : 0), o.bb);
+    };
+    unsigned stage = 0;                                                     // parity = the weight image and the ring half the current stage reads
+    Task cur, nxt;
+    bool have_next = false;
+    unsigned voff = 0, voff_n = 0;
+    auto task_of = [&](int sel) __attribute__((always_inline)) -> const Task & { return sel ? nxt : cur; };
+    auto stage_next = [&](Stage st) __attribute__((always_inline)) {          // the stage after st (the workgroup's last stage: itself)
+        const int nK = st.sel ? nxt.nKmax : cur.nKmax;
+        Stage r = st;
+        if (st.kb + 1 < nK) r.kb = st.kb + 1;
+        else if (st.cls < 3) { r.cls = st.cls + 1; r.kb = 0; }
+        else if (st.sel == 0 && have_next) { r.sel = 1; r.cls = 0; r.kb = 0; }
+        r.sel = __builtin_amdgcn_readfirstlane(r.sel); r.cls = __builtin_amdgcn_readfirstlane(r.cls); r.kb = __builtin_amdgcn_readfirstlane(r.kb);
+        return r;
+    };
+    // weight chunks of stage st into image `par`
+    auto dma_weights = [&](Stage st, unsigned par) __attribute__((always_inline)) {
+        const Task &t = task_of(st.sel);
+        xd_gptr wk = t.ws + ((unsigned)st.cls * cls_bytes + (unsigned)st.kb * (unsigned)(XD_STAGE_A * 4));
+        const unsigned dst = xd_lds_addr(ringA + (par & 1u) * XD_STAGE_A);
+        static_for<NA_DMA>([&](auto jj) {
+            constexpr unsigned ch = (unsigned)(WV + 4 * decltype(jj)::value) * 1024u;
+            xd_dma(lane16, wk + ch, dst + ch);
+        });
+    };
+    // unit U of stage st into this wave's ring half `par`
+    auto dma_unit = [&](auto uu, Stage st, unsigned par) __attribute__((always_inline)) {
+        constexpr int U = decltype(uu)::value, DA = unit_da(U), DB = unit_db(U) >= 0 ? unit_db(U) : unit_da(U);   // (the sixth unit fetches diagonal 10 twice)
+        const Task &t = task_of(st.sel);
+        xd_gptr xk = t.xs + (unsigned)st.kb * kbx;
+        const unsigned ga = (unsigned)(st.cls + XD_C0 + 16 - DA) & 3u, gb2 = (unsigned)(st.cls + XD_C0 + 16 - DB) & 3u;   // input channel inside a group: (class - c) mod 4
+        const unsigned sa = (unsigned)DA * hp4 + ga * skp4, sb = (unsigned)DB * hp4 + gb2 * skp4;
+        const unsigned vo = (st.sel ? voff_n : voff) + (lane < 32 ? sa : sb);
+        xd_dma(vo, xk, bring_lds + ((par & 1u) * NU + U) * 1024u);
+    };
+#define XQ_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    // One stage.  Issue order per wave: [weights of stage + 1] then, behind each unit's MFMAs, [unit of stage + 2]: 6 + NA_DMA per stage, so
+    // "all but the 10 + NA_DMA youngest" covers every unit this stage reads, and "all but the 6 youngest" at its end the weights of the next
+    auto body = [&](auto NN, auto ff, Stage st1, Stage st2) __attribute__((always_inline)) {
+        constexpr int N = decltype(NN)::value;
         constexpr bool FIRST = decltype(ff)::value;
         if constexpr (FIRST && N < XD_ND) {                                 // the tiles of the diagonals this body does not walk
 #pragma unroll
             for (int i = xd_tbase(N); i < XD_NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
         }
-        const float *sA = stage_image(stage);
-        const unsigned dst = xd_lds_addr(stage_image(stage + 1));
-        auto hook = [&](auto mm) __attribute__((always_inline)) {
-            constexpr int m = decltype(mm)::value;
-            if constexpr (m % XQ_DSTRIDE == 0 && m / XQ_DSTRIDE < NDMA) {
+        const float *sA = ringA + (stage & 1u) * XD_STAGE_A;
+        const float *rb = bring + (stage & 1u) * (NU * 256);
+        Ops2 ops[2];
+        XQ_VMWAIT(10 + NA_DMA);
+        load_unit(NN, IC<0>{}, ops[0], sA, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_weights(st1, stage + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NU>([&](auto uu) {
+            constexpr int U = decltype(uu)::value;
+            if constexpr (U + 1 < NU) {
+                XQ_VMWAIT(10 + NA_DMA);
                 __builtin_amdgcn_sched_barrier(0);
-                dma_one(IC<m / XQ_DSTRIDE>{}, xk1, wk1, cn1, voff1, dst);
-                __builtin_amdgcn_sched_barrier(0);
+                load_unit(NN, IC<U + 1>{}, ops[(U + 1) & 1], sA, rb + (U + 1) * 256);
             }
-        };
-        XdOps ops[XQ_PF + 1];
-        static_for<(XQ_PF < N ? XQ_PF : N)>([&](auto ii) { load_ops(IC<xd_walk(N, decltype(ii)::value)>{}, ops[decltype(ii)::value], sA); });
-        static_for<N>([&](auto ii) {
-            constexpr int i = decltype(ii)::value, dc = xd_walk(N, i);
-            constexpr int m0 = [] { int m = 0; for (int j = 0; j < i; ++j) m += 2 * xd_ntiles(xd_walk(N, j)); return m; }();
-            if constexpr (i + XQ_PF < N) load_ops(IC<xd_walk(N, i + XQ_PF)>{}, ops[(i + XQ_PF) % (XQ_PF + 1)], sA);
             __builtin_amdgcn_sched_barrier(0);
-            fma(IC<dc>{}, IC<m0>{}, ff, ops[i % (XQ_PF + 1)], hook);
+            fma_unit(NN, uu, ff, ops[U & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_unit(uu, st2, stage);                                       // the slot just read: stage + 2 has this stage's parity
             __builtin_amdgcn_sched_barrier(0);
         });
-        constexpr int HOOKED = (NM + XQ_DSTRIDE - 1) / XQ_DSTRIDE;
-        static_for<(HOOKED < NDMA ? NDMA - HOOKED : 0)>([&](auto rr) { dma_one(IC<HOOKED + decltype(rr)::value>{}, xk1, wk1, cn1, voff1, dst); });
         XD_T(1);
-        XD_WAIT0();
+        XQ_VMWAIT(6);
         XD_T(7);
         __syncthreads();
         XD_T(8);
         ++stage;
     };
-    Task cur, nxt;
     if (!decode(0, cur)) return;                                            // (uniform over the workgroup)
-    unsigned voff = dma_lane_offset(cur);
-    {
-        const unsigned dst = xd_lds_addr(stage_image(0));
-        static_for<NDMA>([&](auto jj) { dma_one(jj, cur.xs, cur.ws, 0, voff, dst); });
+    voff = dma_lane_offset(cur);
+    have_next = decode(1, nxt);
+    voff_n = have_next ? dma_lane_offset(nxt) : voff;
+    {   // stages 0 and 1 of the first task: weights of stage 0, activations of both
+        const Stage s0 = {0, 0, 0}, s1 = stage_next(s0);
+        dma_weights(s0, 0);
+        static_for<NU>([&](auto uu) { dma_unit(uu, s0, 0); });
+        static_for<NU>([&](auto uu) { dma_unit(uu, s1, 1); });
         XD_WAIT0();
         __syncthreads();
     }
     for (int kt = 0;; ++kt) {
         const int tc0 = cur.tc0, s0 = cur.s0, n_w = cur.n_w, net = cur.net, pbase = cur.pbase;
         const bool span = cur.span, valid_w = cur.valid_w;
-        const bool have_next = decode(kt + 1, nxt);
-        const unsigned voff_n = have_next ? dma_lane_offset(nxt) : voff;
 #ifndef XQ_NCLS
 #define XQ_NCLS 4
 #endif
@@ -899,54 +942,22 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
             constexpr int CLS = decltype(cc)::value;
             XD_T(0);
             {
-                xd_gptr xk = cur.xs, wk = cur.ws + (unsigned)CLS * cls_bytes;
                 const int X = cur.X;
                 int nKmax = cur.nKmax;
                 asm volatile("" : "+s"(nKmax));
                 int kb = 0, D = X;
                 asm volatile("" : "+s"(D));                                     // (uniform: the first block's body is chosen by a scalar branch)
-                // the stage after block kb of class CLS: block kb + 1; or block 0 of the next class; or of the next task's class 0 (none: itself)
-                auto next_stage = [&](xd_gptr &xk1, xd_gptr &wk1, int &cn1, unsigned &v1) __attribute__((always_inline)) {
-                    const bool inner = kb + 1 < nKmax;
-                    if constexpr (CLS < 3) {
-                        xk1 = inner ? xk + kbx : cur.xs;
-                        wk1 = inner ? wk + (unsigned)(XD_STAGE_A * 4) : cur.ws + (unsigned)(CLS + 1) * cls_bytes;
-                        cn1 = inner ? CLS : CLS + 1;
-                        v1 = voff;
-                    } else {
-                        xk1 = inner ? xk + kbx : (have_next ? nxt.xs : xk);
-                        wk1 = inner ? wk + (unsigned)(XD_STAGE_A * 4) : (have_next ? nxt.ws : wk);
-                        cn1 = inner || !have_next ? CLS : 0;
-                        v1 = inner ? voff : voff_n;
-                    }
-                    cn1 = __builtin_amdgcn_readfirstlane(cn1);
-                    asm volatile("" : "+s"(xk1), "+s"(wk1));
+                auto run = [&](auto NN, auto ff) __attribute__((always_inline)) {
+                    const Stage st = {0, CLS, kb}, st1 = stage_next(st), st2 = stage_next(st1);
+                    body(NN, ff, st1, st2);
                 };
                 // the first block starts the chains (X >= 7: eleven live diagonals, or seven for group block 0 of a hidden layer)
-                {
-                    xd_gptr xk1, wk1; int cn1; unsigned v1;
-                    next_stage(xk1, wk1, cn1, v1);
-                    if (D >= 8) body(IC<XD_ND>{}, IC<true>{}, xk1, wk1, cn1, v1);
-                    else body(IC<7>{}, IC<true>{}, xk1, wk1, cn1, v1);      // (X >= 7 always: 4 + hidden + XD_C0 + tc0, hidden layers only reach X = 7 at group block 0; X = 6 (first-layer rule) runs one dead diagonal)
-                    xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4); ++kb; D -= 4;
-                }
-                for (; kb < nKmax && D >= 8; ++kb, D -= 4) {
-                    xd_gptr xk1, wk1; int cn1; unsigned v1;
-                    next_stage(xk1, wk1, cn1, v1);
-                    body(IC<XD_ND>{}, IC<false>{}, xk1, wk1, cn1, v1);
-                    xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4);
-                }
-                if (kb < nKmax && D >= 4) {
-                    xd_gptr xk1, wk1; int cn1; unsigned v1;
-                    next_stage(xk1, wk1, cn1, v1);
-                    body(IC<7>{}, IC<false>{}, xk1, wk1, cn1, v1);
-                    xk = xk + kbx; wk = wk + (unsigned)(XD_STAGE_A * 4); ++kb; D -= 4;
-                }
-                if (kb < nKmax) {
-                    xd_gptr xk1, wk1; int cn1; unsigned v1;
-                    next_stage(xk1, wk1, cn1, v1);
-                    body(IC<3>{}, IC<false>{}, xk1, wk1, cn1, v1);
-                }
+                if (D >= 8) run(IC<XD_ND>{}, IC<true>{});
+                else run(IC<7>{}, IC<true>{});
+                ++kb; D -= 4;
+                for (; kb < nKmax && D >= 8; ++kb, D -= 4) run(IC<XD_ND>{}, IC<false>{});
+                if (kb < nKmax && D >= 4) { run(IC<7>{}, IC<false>{}); ++kb; D -= 4; }
+                if (kb < nKmax) run(IC<3>{}, IC<false>{});
             }
             // ---- halo of the two row halves of a sample (span tasks), then realignment + the reference tree inside the class
             if (span) {
@@ -1056,14 +1067,18 @@ __device__ __forceinline__ void xq_body(const XdArgs &a, float *ring, float *hal
         if (!have_next) break;
         cur = nxt;
         voff = voff_n;
+        have_next = decode(kt + 2, nxt);
+        voff_n = have_next ? dma_lane_offset(nxt) : voff;
     }
+    XD_WAIT0();                                                             // no DMA may outlive the workgroup's LDS
 #ifdef XD_STAMP
     if (lane == 0) for (int i = 0; i < 10; ++i) xd_stamps[((blockIdx.x & 255) * 8 + (blockIdx.x >> 8) * 4 + WV) * 10 + i] += st[i];
 #endif
 }
 
 __global__ __launch_bounds__(XQ_THREADS, 2) void k_cconv16dq(XdArgs a) {
-    __shared__ __attribute__((aligned(16))) float ring[2 * XQ_IMG];          // two stage images: 56 KB
+    __shared__ __attribute__((aligned(16))) float ringA[2 * XD_STAGE_A];     // two weight images: 12 KB
+    __shared__ __attribute__((aligned(16))) float ringB[4 * 2 * 6 * 256];    // per wave: two stages x six 1 KB units of its own input rows: 48 KB
     __shared__ float halo[(2 * 2 + 1) * XD_NHALO * 4];                      // [direction][wave pair][register][channel] + a block of zeros
     __shared__ float hs[4 * XD_GB * 2 * 2 * 64];                            // [wave][group][output row][class parity][lane]
     for (int i = threadIdx.x; i < XD_NHALO * 4; i += XQ_THREADS) halo[2 * 2 * XD_NHALO * 4 + i] = 0.f;
@@ -1071,10 +1086,10 @@ __global__ __launch_bounds__(XQ_THREADS, 2) void k_cconv16dq(XdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     switch (wave) {
-        case 0: xq_body<0>(a, ring, halo, hs, lane); break;
-        case 1: xq_body<1>(a, ring, halo, hs, lane); break;
-        case 2: xq_body<2>(a, ring, halo, hs, lane); break;
-        default: xq_body<3>(a, ring, halo, hs, lane); break;
+        case 0: xq_body<0>(a, ringA, ringB, halo, hs, lane); break;
+        case 1: xq_body<1>(a, ringA, ringB, halo, hs, lane); break;
+        case 2: xq_body<2>(a, ringA, ringB, halo, hs, lane); break;
+        default: xq_body<3>(a, ringA, ringB, halo, hs, lane); break;
     }
 }
 
