@@ -1049,3 +1049,59 @@ ORC_API void orc_viewport_xy(const float *theta_phi_next, const float *rota, flo
         xy[2 * i + 1] = (float)(-gamma * (xa * y[2] + xb * y[5] + xc * y[8]) - 0.5 + y_bias);
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * f1: the pieces of the analysis / synthesis transforms that are plain torch in the reference
+ * (test/model_zoo.py:8-105,145-170: nn.Conv2d, nn.PReLU, nn.Sigmoid; lic360_operator/GDN.py:66-100), restated in fp32 so
+ * that the -m gpu tests of lic360_models.py have a CPU oracle and not only a torch expression.  The library convolution's
+ * summation order is not specified (cuDNN there, MIOpen here): this restatement fixes ONE order -- bias first, then input
+ * channel major, kernel row, kernel column, one fmaf per term -- and the tests compare within 1e-4.
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_conv2d(const float *x, const float *w, const float *b, float *out, int N, int Cin, int H, int W, int Cout,
+                        int k, int stride, int pad) {
+    int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    long total = (long)N * Cout * Ho;
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < total; ++r) {
+        int ho = (int)(r % Ho), co = (int)((r / Ho) % Cout), n = (int)(r / ((long)Ho * Cout));
+        for (int wo = 0; wo < Wo; ++wo) {
+            float s = b ? b[co] : 0.0f;
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int kh = 0; kh < k; ++kh) {
+                    int hi = ho * stride - pad + kh;
+                    if (hi < 0 || hi >= H) continue;
+                    for (int kw = 0; kw < k; ++kw) {
+                        int wi = wo * stride - pad + kw;
+                        if (wi < 0 || wi >= W) continue;
+                        s = fmaf(x[(((long)n * Cin + ci) * H + hi) * W + wi], w[(((long)co * Cin + ci) * k + kh) * k + kw], s);
+                    }
+                }
+            out[(((long)n * Cout + co) * Ho + ho) * Wo + wo] = s;
+        }
+    }
+}
+/* nn.PReLU(C): y = x > 0 ? x : a[c] x */
+ORC_API void orc_prelu(const float *x, const float *a, float *out, int N, int C, long HW) {
+    long total = (long)N * C * HW;
+    for (long i = 0; i < total; ++i) {
+        int c = (int)((i / HW) % C);
+        out[i] = x[i] > 0 ? x[i] : a[c] * x[i];
+    }
+}
+/* GDN.py:88-97 on the EFFECTIVE parameters (the caller applies the lower bounds and the pedestal, GDN.py:81-86):
+ * norm[c] = sqrt(beta[c] + sum_j gamma[c][j] x[j]^2)  (j ascending, fmaf);  y = x / norm, or x * norm (inverse) */
+ORC_API void orc_gdn(const float *x, const float *gamma, const float *beta, float *out, int N, int C, long HW, int inverse) {
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < (long)N * HW; ++p) {
+        long n = p / HW, q = p % HW;
+        for (int c = 0; c < C; ++c) {
+            float s = beta[c];
+            for (int j = 0; j < C; ++j) {
+                float v = x[(n * C + j) * HW + q];
+                s = fmaf(gamma[(long)c * C + j], v * v, s);
+            }
+            float nr = sqrtf(s), xv = x[(n * C + c) * HW + q];
+            out[(n * C + c) * HW + q] = inverse ? xv * nr : xv / nr;
+        }
+    }
+}

@@ -508,3 +508,82 @@ def viewport_xy(theta_phi_next, rota, ho, wo, fov_deg):
     xy = np.empty((n, 2), np.float32)
     lib.orc_viewport_xy(f32(theta_phi_next), f32(rota), xy, n, ho, wo, fov_deg)
     return xy
+
+
+# ---------------------------------------------------------------- f1: transform blocks (test/model_zoo.py:8-105,145-170; GDN.py:66-100)
+lib.orc_conv2d.argtypes = [_f, _f, _PF, _f] + [C.c_int] * 8
+lib.orc_prelu.argtypes = [_f, _f, _f, C.c_int, C.c_int, C.c_long]
+lib.orc_gdn.argtypes = [_f, _f, _f, _f, C.c_int, C.c_int, C.c_long, C.c_int]
+
+
+def conv2d(x, w, b, stride=1, pad=0):
+    x, w = f32(x), f32(w)
+    N, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    b = None if b is None else f32(b)
+    out = np.empty((N, Cout, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1), np.float32)
+    lib.orc_conv2d(x, w, _fp(b), out, N, Cin, H, W, Cout, k, stride, pad)
+    return out
+
+
+def prelu(x, a):
+    x = f32(x)
+    out = np.empty_like(x)
+    lib.orc_prelu(x, f32(a), out, x.shape[0], x.shape[1], x.shape[2] * x.shape[3])
+    return out
+
+
+def gdn(x, gamma_eff, beta_eff, inverse=False):
+    x = f32(x)
+    out = np.empty_like(x)
+    lib.orc_gdn(x, f32(gamma_eff), f32(beta_eff), out, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], int(inverse))
+    return out
+
+
+def gdn_effective(gamma, beta, pedestal, beta_bound, gamma_bound):
+    """the reparametrisation of GDN.py:81-86: lower bound, square, minus the pedestal (fp32, in that order)"""
+    g = np.maximum(f32(gamma), np.float32(gamma_bound))
+    bt = np.maximum(f32(beta), np.float32(beta_bound))
+    return (g * g - np.float32(pedestal)).astype(np.float32), (bt * bt - np.float32(pedestal)).astype(np.float32)
+
+
+class blocks:
+    """The reference's transform blocks over the oracle's ops.  p: dict of numpy parameters with the block's state_dict keys
+    (conv1.weight, relu1.weight, relu2.gamma / relu2.beta + its `gdn` constants ...).  Inputs carry a 2-cell sphere apron."""
+
+    @staticmethod
+    def _gdn(y, p, pre, inverse):
+        ge, be = gdn_effective(p[pre + ".gamma"], p[pre + ".beta"], p[pre + ".pedestal"], p[pre + ".beta_bound"], p[pre + ".gamma_bound"])
+        return gdn(y, ge, be, inverse)
+
+    @staticmethod
+    def residual(x, p):                                   # model_zoo.py:8-23
+        y = sphere_pad_inplace(f32(x).copy(), 2)
+        y = prelu(conv2d(y, p["conv1.weight"], p["conv1.bias"]), p["relu1.weight"])
+        y = prelu(conv2d(y, p["conv2.weight"], p["conv2.bias"], 1, 1), p["relu2.weight"])
+        return sphere_trim((sphere_pad_inplace(f32(x).copy(), 2) + conv2d(y, p["conv3.weight"], p["conv3.bias"])).astype(np.float32), 2)
+
+    @staticmethod
+    def residual_v2(x, p):                                # model_zoo.py:48-64
+        y = sphere_pad_inplace(f32(x).copy(), 2)
+        y = sphere_trim(prelu(conv2d(y, p["conv1.weight"], p["conv1.bias"], 1, 1), p["relu1.weight"]), 1)
+        y = sphere_trim(prelu(conv2d(y, p["conv2.weight"], p["conv2.bias"], 1, 1), p["relu2.weight"]), 2)
+        return (sphere_pad_inplace(f32(x).copy(), 2) + y).astype(np.float32)
+
+    @staticmethod
+    def residual_down(x, p):                              # model_zoo.py:66-95, hidden = True
+        t = conv2d(x, p["short_cut.weight"], p["short_cut.bias"], 2, 2)
+        y = sphere_pad_inplace(f32(x).copy(), 2)
+        y = sphere_trim(prelu(conv2d(y, p["conv1.weight"], p["conv1.bias"], 2, 3), p["relu1.weight"]), 2)
+        y = sphere_pad_inplace(y, 2)
+        y = blocks._gdn(conv2d(y, p["conv2.weight"], p["conv2.bias"], 1, 1), p, "relu2", False)
+        return sphere_trim((t + y).astype(np.float32), 2)
+
+    @staticmethod
+    def residual_up(x, p):                                # model_zoo.py:145-170
+        y = sphere_pad_inplace(f32(x).copy(), 2)
+        b = prelu(conv2d(y, p["conv1.weight"], p["conv1.bias"]), p["relu1.weight"])
+        b = sphere_pad_inplace(sphere_trim(dtow(b, 2, True), 2), 2)
+        b = blocks._gdn(conv2d(b, p["conv2.weight"], p["conv2.bias"], 1, 1), p, "relu2", True)
+        s = dtow(conv2d(sphere_cut_edge(y, 1), p["short_cut.weight"], p["short_cut.bias"]), 2, True)
+        return sphere_trim((b + s).astype(np.float32), 2)

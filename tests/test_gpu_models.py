@@ -84,6 +84,40 @@ def test_blocks_match_index_only_torch(lic):
         assert torch.allclose(up(x.clone()), want, rtol=1e-4, atol=1e-4)
 
 
+def _block_params(blk):
+    """numpy parameters of a block under its state_dict keys + the constants of its GDN (the oracle's `blocks` take these)"""
+    p = {k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    for name, m in blk.named_modules():
+        if type(m).__name__ == "GDN":
+            p[name + ".pedestal"], p[name + ".beta_bound"], p[name + ".gamma_bound"] = m.pedestal, m.beta_bound, m.gamma_bound
+    return p
+
+
+def test_blocks_match_the_oracle(lic):
+    """ResidualBlock / ResidualBlockV2 / ResidualBlockDown / ResidualBlockUp (test/model_zoo.py:8-95,145-170) against the CPU oracle's
+    restatement of the same blocks (oracle.blocks: orc_conv2d / orc_prelu / orc_gdn + the sphere ops' and pixel shuffle's restatements).
+    The convolutions are MIOpen's here and cuDNN's in the reference: neither fixes a summation order, so the comparison is 1e-4, not
+    bit-exact; everything around them (aprons, trims, shuffles, the residual wiring) is exact and would show as O(1) errors."""
+    import oracle as orc
+    import lic360_models as lm
+    torch.manual_seed(5)
+    c = 16
+    x = _refresh(torch.randn((2, c, 12, 20), device="cuda:0"))              # maps with a valid 2-cell apron
+    xn = x.cpu().numpy()
+    with torch.no_grad():
+        for cls, fn in ((lm.ResidualBlock, orc.blocks.residual), (lm.ResidualBlockV2, orc.blocks.residual_v2),
+                        (lambda ch, d: lm.ResidualBlockDown(ch, ch, d), orc.blocks.residual_down), (lm.ResidualBlockUp, orc.blocks.residual_up)):
+            blk = cls(c, 0).to("cuda:0")
+            for prm in blk.parameters():                                    # PReLU slopes / GDN parameters away from their symmetric defaults
+                if prm.dim() <= 2:
+                    prm.add_(0.05 * torch.rand_like(prm))
+            got = blk(x.clone()).cpu().numpy()
+            want = fn(xn.copy(), _block_params(blk))
+            assert got.shape == want.shape, (got.shape, want.shape)
+            err = np.abs(got - want).max()
+            assert np.allclose(got, want, rtol=1e-4, atol=1e-4), "%s: max abs error %g" % (type(blk).__name__, err)
+
+
 def test_state_dict_layout_is_the_references(lic):
     import lic360_models as lm
     enc, dec = lm.CMP_Encoder(32, 32, 8, 0), lm.CMP_Decoder(32, 32, 8, 0)
