@@ -192,7 +192,9 @@ def dry_run(args):
 
 
 def run_rank(args):
-    os.environ.setdefault("OMP_NUM_THREADS", str(host_cpu()[0]))     # the oracle's pool (cpu_baseline leg only): every host core of this process
+    # the oracle's pool (cpu_baseline leg only): the GPU box shares its host cores between its GPUs (16 per GPU); with all 256 hardware
+    # threads of the box the same leg took 75 s instead of 25-45 s.  `cores` is what was used, `nproc` / `cpu_model` what the box has.
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, host_cpu()[0])))
     import numpy as np
     import torch
     import torch.distributed as dist

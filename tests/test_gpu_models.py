@@ -84,6 +84,40 @@ def test_blocks_match_index_only_torch(lic):
         assert torch.allclose(up(x.clone()), want, rtol=1e-4, atol=1e-4)
 
 
+def test_block_gradients_match_index_only_torch(lic):
+    """the in-place SpherePad / SphereTrim wrappers return their input without mark_dirty (as the reference's do), which is
+    only sound if every tensor a convolution saved for backward still holds what it read.  Parameter AND input gradients of the blocks
+    that refresh / trim in place (ResidualBlockV2, ResidualBlockDown, the three-deep trunk of AttentionBlock) against the same blocks
+    written with index-only, out-of-place torch operations on the same weights."""
+    import lic360_models as lm
+    torch.manual_seed(9)
+    c = 16
+    x0 = _refresh(torch.randn((1, c, 12, 20), device="cuda:0"))
+
+    def grads(fn, params):
+        x = x0.clone().requires_grad_(True)
+        out = fn(x)
+        g = torch.sin(torch.arange(out.numel(), device="cuda:0", dtype=torch.float32)).view_as(out)
+        return torch.autograd.grad((out * g).sum(), [x] + params, allow_unused=False)
+
+    v2 = lm.ResidualBlockV2(c, 0).to("cuda:0")
+    ref_v2 = lambda x: _refresh(x) + _trim(v2.relu2(v2.conv2(_trim(v2.relu1(v2.conv1(_refresh(x))), 1))), 2)
+    dn = lm.ResidualBlockDown(c, c, 0).to("cuda:0")
+    gdn = dn.relu2
+
+    def ref_dn(x):
+        y = _refresh(_trim(dn.relu1(dn.conv1(_refresh(x))), 2))
+        return _trim(dn.short_cut(x) + gdn(dn.conv2(y)), 2)
+    rb = lm.ResidualBlock(c, 0).to("cuda:0")
+    ref_rb = lambda x: _trim(_refresh(x) + rb.conv3(rb.relu2(rb.conv2(rb.relu1(rb.conv1(_refresh(x)))))), 2)
+    for blk, ref in ((v2, ref_v2), (dn, ref_dn), (rb, ref_rb)):
+        params = [q for q in blk.parameters()]
+        got = grads(lambda x: blk(x * 1.0), params)                          # (x * 1.0: the block works in place on its input)
+        want = grads(ref, params)
+        for a, b, name in zip(got, want, ["input"] + [n for n, _ in blk.named_parameters()]):
+            assert torch.allclose(a, b, rtol=2e-3, atol=2e-4), "%s %s: max abs diff %g" % (type(blk).__name__, name, float((a - b).abs().max()))
+
+
 def _block_params(blk):
     """numpy parameters of a block under its state_dict keys + the constants of its GDN (the oracle's `blocks` take these)"""
     p = {k: v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
