@@ -1129,381 +1129,3 @@ LIC360_API int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *p, 
     LAUNCH_CHECK();
     return 0;
 }
-
-// ================================================================================================ one column tile per wave (round 4, third form)
-// k_cconv16dt: k_cconv16dq with HALF the accumulators per wave.  What bounds the two forms above is neither operand fetch nor the K loop
-// (k_cconv16dq's is matrix-pipe-bound) but the third of a wave's life in which it issues no MFMA (tree, halo, set-up, stores) while its
-// only SIMD partner cannot fill the pipe alone -- and 192 accumulator registers allow no third wave.  Here a wave owns ONE 16-row column
-// tile (rows base + n, no interleave): 96 accumulators, <= 168 registers, THREE waves per SIMD from three independent 4-wave
-// workgroups per CU.  A workgroup = the four row quarters of one sample's 64-row diagonals -- or 2 samples x 2 quarters (windows of
-// <= 32 rows), or 4 samples (<= 16 rows) --, class-sequential like k_cconv16dq; a stage's weights are shared by the four waves, each
-// wave's activations come into its private two-stage ring in units of four diagonals (1 KB: lane = 64 w + 16 plane + row quad... see
-// dma_lane_offset; the reader's float index inside a unit is simply 64 w + lane).  The realignment by kh - 2 is one DPP row shift
-// by 1 or 2 lanes whose edge lanes come from the neighbouring quarter's halo (same 45 values per direction as above).
-#define XT_THREADS 256
-#define XT_NU 3                                 // activation units (4 diagonals each) per stage
-__host__ __device__ constexpr int xt_unit_diag(int u, int w) {                // walk 5,4,6,3 | 7,2,8,1 | 9,0,10 (the last slot repeats 10)
-    constexpr int t[3][4] = {{5, 4, 6, 3}, {7, 2, 8, 1}, {9, 0, 10, 10}};
-    return t[u][w];
-}
-__host__ __device__ constexpr int xt_walk(int i) { return xt_unit_diag(i / 4, i % 4); }   // i < 11
-
-template <int WV>
-__device__ __forceinline__ void xt_body(const XdArgs &a, float *ringA, float *ringB, float *halo, float *hs_all, const int lane) {
-    float *const hs = hs_all + WV * (XD_GB * 2 * 64) + lane;                // this lane's class partials [group][class parity]
-    constexpr int NA_DMA = WV < 2 ? 2 : 1;                                  // this wave's share of a stage's six weight chunks (chunk WV + 4 j)
-    const int G = a.G, H = a.H, W = a.W, S = H + W - 1, C = G * 4, nout = G * a.cout, HP = a.HP;
-    const long SKP = a.SKP;
-    const int n16 = lane & 15, kl = lane >> 4;
-    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x - xcd + 7) >> 3;
-    const int spn = a.npb >> 3, nb = a.N / a.npb;                           // samples per stacked net and XCD: n = xcd + 8 i
-    // window of group block gb: first input row and row count of what its (up to) three diagonals read
-    auto window_of = [&](int gb, int &t0) __attribute__((always_inline)) {
-        int lo = 1 << 30, hi = -1;
-#pragma unroll
-        for (int q = 0; q < XD_GB; ++q) {
-            const int g = gb * XD_GB + q, sq = a.psum - g;
-            const int l = sq >= W ? sq - W + 1 : 0, hh = sq < H ? sq : H - 1;
-            if (g < G && sq >= 0 && sq < S) { lo = l < lo ? l : lo; hi = hh > hi ? hh : hi; }
-        }
-        const int lo_in = lo - 2 > 0 ? lo - 2 : 0, hi_in = hi + 2 < H - 1 ? hi + 2 : H - 1;
-        t0 = lo_in;
-        return hi_in - lo_in + 1;
-    };
-    // mode of a block: 0 = one sample on rows 0..63 (four quarters), 1 = two samples x two quarters, 2 = four samples x one quarter
-    unsigned m1 = 0, m2 = 0;
-    for (int j = 0; j < a.n_gbv; ++j) {
-        int t0;
-        const int rows = window_of(a.gb_hi - j, t0);
-        m1 |= (rows <= 32 && rows > 16 ? 1u : 0u) << j;
-        m2 |= (rows <= 16 ? 1u : 0u) << j;
-    }
-    m1 = __builtin_amdgcn_readfirstlane(m1); m2 = __builtin_amdgcn_readfirstlane(m2);
-    auto mode_of = [&](int j) __attribute__((always_inline)) { return (int)((m1 >> j) & 1u) + 2 * (int)((m2 >> j) & 1u); };
-    auto upn_of = [&](int mode) __attribute__((always_inline)) { return mode == 0 ? spn : (mode == 1 ? (spn + 1) >> 1 : (spn + 3) >> 2); };
-    auto units_of = [&](int j) __attribute__((always_inline)) { return nb * upn_of(mode_of(j)); };
-    int n_my = 0;
-    for (int j = 0; j < a.n_gbv; ++j) n_my += units_of(j);
-    const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#ifdef XD_STAMP
-    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
-#endif
-    struct Task {
-        int tc0, s0, n_w, net, pbase, X, nKmax, gb;
-        bool valid_w, above, below;                                         // a neighbouring quarter of the same sample with lower / higher rows
-        xd_gptr xs, ws;
-    };
-    int scan_j = 0, scan_base = 0;
-    auto decode = [&](int kt, Task &t) __attribute__((always_inline)) {
-        const int u = kt * wgs_per_xcd + ((kt & 1) ? wgs_per_xcd - 1 - wg_in_xcd : wg_in_xcd);
-        if (u >= n_my) return false;
-        while (scan_j < a.n_gbv - 1 && u >= scan_base + units_of(scan_j)) { scan_base += units_of(scan_j); ++scan_j; }   // (u grows with kt)
-        const int gb = a.gb_hi - scan_j, mode = mode_of(scan_j), upn = upn_of(mode);
-        int rem = u - scan_base, net = 0;
-        while (rem >= upn) { rem -= upn; ++net; }
-        t.net = net; t.gb = gb;
-        t.tc0 = gb * XD_GB; t.s0 = a.psum - t.tc0;
-        int T0;
-        (void)window_of(gb, T0);
-        if (mode == 0) T0 = 0;
-        // this wave's sample (index in the net's list of the XCD) and row quarter
-        const int j = mode == 0 ? rem : (mode == 1 ? 2 * rem + (WV >> 1) : 4 * rem + WV);
-        const int quarter = mode == 0 ? WV : (mode == 1 ? (WV & 1) : 0);
-        t.valid_w = j < spn;
-        const int js = t.valid_w ? j : (mode == 1 ? 2 * rem : 4 * rem);       // a slot past the list recomputes the unit's first sample and stores nothing
-        t.n_w = xcd + 8 * (net * spn + js);
-        t.pbase = T0 + 16 * quarter;
-        t.above = quarter > 0;
-        t.below = mode == 0 ? WV < 3 : (mode == 1 ? (WV & 1) == 0 : false);
-        t.X = __builtin_amdgcn_readfirstlane(t.tc0 + 4 + a.hidden + XD_C0);
-        t.nKmax = __builtin_amdgcn_readfirstlane(((t.X < G ? t.X : G) + 3) >> 2);
-        const int iw = t.n_w < a.x_mod ? t.n_w : t.n_w % a.x_mod;
-        t.xs = (xd_gptr)(a.x + (long)iw * C * SKP + (long)t.s0 * HP + XD_COL0);
-        t.ws = (xd_gptr)(a.packed + (((long)net * a.ngb_all + gb) * 4 * a.NKB) * XD_STAGE_A);
-        return true;
-    };
-    const unsigned lane16 = (unsigned)lane * 16u;
-    float *const bring = ringB + WV * (2 * XT_NU * 256);
-    const unsigned bring_lds = xd_lds_addr(bring);
-    // B unit: lane l = 16 w + 4 k + m fetches rows pbase + 4 m .. + 3 of channel plane k of the unit's w-th diagonal into slot bytes [16 l, +16)
-    auto dma_lane_offset = [&](const Task &t) __attribute__((always_inline)) -> unsigned {
-        const int k = (lane >> 2) & 3, m = lane & 3;
-        int r = t.pbase + 4 * m;
-        if (r >= H + 2) r = H - 2 > 0 ? H - 2 : 0;                           // stay inside the sample's planes (rows behind the image reach no stored output)
-        return (unsigned)((4 * k * (int)SKP + r) * 4);
-    };
-    const unsigned hp4 = (unsigned)HP * 4u, skp4 = (unsigned)SKP * 4u, kbx = 16u * skp4;
-    const unsigned cls_bytes = (unsigned)a.NKB * (XD_STAGE_A * 4);
-    struct Stage { int sel, cls, kb; };
-    f32x4 acc[XD_NT];
-    struct Ops1 { float a[4]; float b; };
-    auto load_ops = [&](auto ii, Ops1 &o, const float *sA, const float *rb) __attribute__((always_inline)) {
-        constexpr int i = decltype(ii)::value, dc = xt_walk(i), T = xd_ntiles(dc), tb = xd_tbase(dc);
-        const float *p = sA + tb * 64;
-        if constexpr (T == 1) o.a[0] = p[lane];
-        else if constexpr (T == 2) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; }
-        else if constexpr (T == 3) { const xd_f2 v = *(const xd_f2 *)(p + 2 * lane); o.a[0] = v.x; o.a[1] = v.y; o.a[2] = p[128 + lane]; }
-        else { const f32x4 v = *(const f32x4 *)(p + 4 * lane); o.a[0] = v[0]; o.a[1] = v[1]; o.a[2] = v[2]; o.a[3] = v[3]; }
-        o.b = rb[(i / 4) * 256 + (i % 4) * 64 + lane];
-    };
-    unsigned stage = 0;
-    Task cur, nxt;
-    bool have_next = false;
-    unsigned voff = 0, voff_n = 0;
-    auto task_of = [&](int sel) __attribute__((always_inline)) -> const Task & { return sel ? nxt : cur; };
-    auto stage_next = [&](Stage st) __attribute__((always_inline)) {
-        const int nK = st.sel ? nxt.nKmax : cur.nKmax;
-        Stage r = st;
-        if (st.kb + 1 < nK) r.kb = st.kb + 1;
-        else if (st.cls < 3) { r.cls = st.cls + 1; r.kb = 0; }
-        else if (st.sel == 0 && have_next) { r.sel = 1; r.cls = 0; r.kb = 0; }
-        r.sel = __builtin_amdgcn_readfirstlane(r.sel); r.cls = __builtin_amdgcn_readfirstlane(r.cls); r.kb = __builtin_amdgcn_readfirstlane(r.kb);
-        return r;
-    };
-    auto dma_weights = [&](Stage st, unsigned par) __attribute__((always_inline)) {
-        const Task &t = task_of(st.sel);
-        xd_gptr wk = t.ws + ((unsigned)st.cls * cls_bytes + (unsigned)st.kb * (unsigned)(XD_STAGE_A * 4));
-        const unsigned dst = xd_lds_addr(ringA + (par & 1u) * XD_STAGE_A);
-        static_for<NA_DMA>([&](auto jj) {
-            constexpr unsigned ch = (unsigned)(WV + 4 * decltype(jj)::value) * 1024u;
-            xd_dma(lane16, wk + ch, dst + ch);
-        });
-    };
-    auto dma_unit = [&](auto uu, Stage st, unsigned par) __attribute__((always_inline)) {
-        constexpr int U = decltype(uu)::value;
-        const Task &t = task_of(st.sel);
-        xd_gptr xk = t.xs + (unsigned)st.kb * kbx;
-        // per diagonal of the unit: its row in the band + the class's input channel (class - c) mod 4
-        constexpr int D0 = xt_unit_diag(U, 0), D1 = xt_unit_diag(U, 1), D2 = xt_unit_diag(U, 2), D3 = xt_unit_diag(U, 3);
-        auto sdiag = [&](int dc) __attribute__((always_inline)) { return (unsigned)dc * hp4 + ((unsigned)(st.cls + XD_C0 + 16 - dc) & 3u) * skp4; };
-        const unsigned s0_ = sdiag(D0), s1_ = sdiag(D1), s2_ = sdiag(D2), s3_ = sdiag(D3);
-        const int w = lane >> 4;
-        const unsigned vo = (st.sel ? voff_n : voff) + (w == 0 ? s0_ : (w == 1 ? s1_ : (w == 2 ? s2_ : s3_)));
-        xd_dma(vo, xk, bring_lds + ((par & 1u) * XT_NU + U) * 1024u);
-    };
-    // One stage.  Issue order per wave: [weights of stage + 1] then, behind each unit's last MFMA, [that unit of stage + 2]: 3 + NA_DMA per
-    // stage -- "all but the 4 + NA_DMA youngest" covers every unit this stage reads, "all but the 3 youngest" at its end the next weights
-    auto body = [&](auto NN, auto ff, Stage st1, Stage st2) __attribute__((always_inline)) {
-        constexpr int N = decltype(NN)::value;
-        constexpr bool FIRST = decltype(ff)::value;
-        if constexpr (FIRST && N < XD_ND) {
-#pragma unroll
-            for (int i = xd_tbase(N); i < XD_NT; ++i) acc[i] = zero4;
-        }
-        const float *sA = ringA + (stage & 1u) * XD_STAGE_A;
-        const float *rb = bring + (stage & 1u) * (XT_NU * 256);
-        constexpr int PF = 2;
-        Ops1 ops[PF + 1];
-        XQ_VMWAIT(4 + NA_DMA);
-        static_for<PF>([&](auto ii) { if constexpr (xt_walk(decltype(ii)::value) < N) load_ops(ii, ops[decltype(ii)::value], sA, rb); });
-        __builtin_amdgcn_sched_barrier(0);
-        dma_weights(st1, stage + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<XD_ND>([&](auto ii) {
-            constexpr int i = decltype(ii)::value, dc = xt_walk(i);
-            if constexpr (i + PF < XD_ND) {
-                if constexpr ((i + PF) % 4 == 0) { XQ_VMWAIT(4 + NA_DMA); __builtin_amdgcn_sched_barrier(0); }   // the first diagonal of the next unit
-                if constexpr (xt_walk(i + PF) < N) load_ops(IC<i + PF>{}, ops[(i + PF) % (PF + 1)], sA, rb);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (dc < N) {
-                constexpr int T = xd_ntiles(dc), tb = xd_tbase(dc);
-                static_for<T>([&](auto tt) {
-                    constexpr int t = decltype(tt)::value;
-                    acc[tb + t] = xd_mfma(ops[i % (PF + 1)].a[t], ops[i % (PF + 1)].b, FIRST ? zero4 : acc[tb + t]);
-                });
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i % 4 == 3 || i == XD_ND - 1) { dma_unit(IC<i / 4>{}, st2, stage); __builtin_amdgcn_sched_barrier(0); }   // the unit just read: stage + 2 has this parity
-        });
-        XD_T(1);
-        XQ_VMWAIT(3);
-        XD_T(7);
-        __syncthreads();
-        XD_T(8);
-        ++stage;
-    };
-    if (!decode(0, cur)) return;                                            // (uniform over the workgroup)
-    voff = dma_lane_offset(cur);
-    have_next = decode(1, nxt);
-    voff_n = have_next ? dma_lane_offset(nxt) : voff;
-    {
-        const Stage s0 = {0, 0, 0}, s1 = stage_next(s0);
-        dma_weights(s0, 0);
-        static_for<XT_NU>([&](auto uu) { dma_unit(uu, s0, 0); });
-        static_for<XT_NU>([&](auto uu) { dma_unit(uu, s1, 1); });
-        XD_WAIT0();
-        __syncthreads();
-    }
-    // halo: [direction 0: a wave's first two columns (for the quarter above) | 1: its last two (for the quarter below)][wave][45 values][4 channels] + zeros
-    constexpr int HZ = 2 * 4 * XD_NHALO * 4;
-    const int j2 = n16 == 15 ? 4 : 0, j2d = n16 == 1 ? 4 : 0;                // second edge column of a two-lane shift (floats)
-    for (int kt = 0;; ++kt) {
-        const int tc0 = cur.tc0, s0 = cur.s0, n_w = cur.n_w, net = cur.net, pbase = cur.pbase;
-        const bool valid_w = cur.valid_w, above = cur.above, below = cur.below;
-        static_for<4>([&](auto cc) {
-            constexpr int CLS = decltype(cc)::value;
-            XD_T(0);
-            {
-                const int X = cur.X;
-                int nKmax = cur.nKmax;
-                asm volatile("" : "+s"(nKmax));
-                int kb = 0, D = X;
-                asm volatile("" : "+s"(D));
-                auto run = [&](auto NN, auto ff) __attribute__((always_inline)) {
-                    const Stage st = {0, CLS, kb}, st1 = stage_next(st), st2 = stage_next(st1);
-                    body(NN, ff, st1, st2);
-                };
-                if (D >= 8) run(IC<XD_ND>{}, IC<true>{});
-                else run(IC<7>{}, IC<true>{});
-                ++kb; D -= 4;
-                for (; kb < nKmax && D >= 8; ++kb, D -= 4) run(IC<XD_ND>{}, IC<false>{});
-                if (kb < nKmax && D >= 4) { run(IC<7>{}, IC<false>{}); ++kb; D -= 4; }
-                if (kb < nKmax) run(IC<3>{}, IC<false>{});
-            }
-            // ---- halo: first columns for the quarter above (its slots shifted towards higher rows), last columns for the one below
-            static_for<2>([&](auto tt) {
-                constexpr int t = decltype(tt)::value;
-                if (above && n16 == t) {
-                    static_for<XD_ND>([&](auto dd) {
-                        constexpr int dc = decltype(dd)::value;
-                        static_for<xd_nslots(dc)>([&](auto ii) {
-                            constexpr int idx = decltype(ii)::value, kh = xd_slot(dc, idx) & 7, tile = xd_tbase(dc) + idx / 4, reg = idx & 3;
-                            if constexpr (xd_halo_has(kh, t, true)) {
-                                constexpr int hid = ((0 * 4 + WV) * XD_NHALO + xd_halo_id(dc, idx, t, true)) * 4;   // (constexpr: else evaluated at run time)
-                                halo[hid + kl] = acc[tile][reg];
-                            }
-                        });
-                    });
-                }
-                if (below && n16 == 14 + t) {
-                    static_for<XD_ND>([&](auto dd) {
-                        constexpr int dc = decltype(dd)::value;
-                        static_for<xd_nslots(dc)>([&](auto ii) {
-                            constexpr int idx = decltype(ii)::value, kh = xd_slot(dc, idx) & 7, tile = xd_tbase(dc) + idx / 4, reg = idx & 3;
-                            if constexpr (xd_halo_has(kh, t, false)) {
-                                constexpr int hid = ((1 * 4 + WV) * XD_NHALO + xd_halo_id(dc, idx, t, false)) * 4;
-                                halo[hid + kl] = acc[tile][reg];
-                            }
-                        });
-                    });
-                }
-            });
-            XD_T(2);
-            __syncthreads();
-            XD_T(3);
-            // edge values: the quarter below's first columns / the quarter above's last columns, or zeros
-            const float *const h_below = halo + (below ? (0 * 4 + (WV + 1 < 4 ? WV + 1 : 3)) * XD_NHALO * 4 : HZ) + kl;
-            const float *const h_above = halo + (above ? (1 * 4 + (WV > 0 ? WV - 1 : 0)) * XD_NHALO * 4 : HZ) + kl;
-            static_for<XD_GB>([&](auto qq) {
-                constexpr int Q = decltype(qq)::value, CQ = (CLS + Q) & 3;
-                auto leaf = [&](auto ii) __attribute__((always_inline)) -> float {
-                    constexpr int i = decltype(ii)::value, tap = i % 25, kh = tap / 5, kw = tap % 5, c = kh + kw - Q, dc = c + XD_C0;
-                    static_assert(dc >= 0 && dc < XD_ND && ((CLS - c + 16) & 3) == i / 25, "leaf i of class CQ lies on diagonal c in channel gid");
-                    constexpr int idx = xd_slot_index(dc, Q, kh), tile = xd_tbase(dc) + idx / 4, reg = idx & 3, dl = kh - 2;
-                    static_assert(idx >= 0, "slot table");
-                    // output row r <- input row r + dl: lane n takes lane n + dl, the lanes past the tile's end the neighbour's edge columns
-                    if constexpr (dl == 0) return acc[tile][reg];
-                    else if constexpr (dl > 0) {
-                        constexpr int hid = xd_halo_id(dc, idx, 0, true) * 4;    // (constexpr: else evaluated at run time)
-                        if constexpr (dl == 1) return xd_row_shift<0x101>(h_below[hid], acc[tile][reg]);
-                        else return xd_row_shift<0x102>(h_below[hid + (below ? j2 : 0)], acc[tile][reg]);
-                    } else if constexpr (dl == -1) {
-                        constexpr int hid = xd_halo_id(dc, idx, 1, false) * 4;
-                        return xd_row_shift<0x111>(h_above[hid], acc[tile][reg]);
-                    } else {
-                        constexpr int hid = xd_halo_id(dc, idx, 0, false) * 4;
-                        return xd_row_shift<0x112>(h_above[hid + (above ? j2d : 0)], acc[tile][reg]);
-                    }
-                };
-                __builtin_amdgcn_sched_barrier(0);
-                const float part = XdTree<CQ, 4>::eval(leaf);
-                constexpr int hi = (Q * 2 + (CQ & 1)) * 64;
-                if constexpr (CLS < 2) hs[hi] = part;
-                else hs[hi] = hs[hi] + part;                                    // F0 + F2 / F1 + F3 (IEEE addition commutes exactly)
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            __syncthreads();                                                // (the halo is rewritten by the next class pass)
-        });
-        XD_T(4);
-        {
-            const int r = pbase + n16, o = kl;
-            static_for<XD_GB>([&](auto qq) {
-                constexpr int Q = decltype(qq)::value;
-                const int g = tc0 + Q, sq = s0 - Q;
-                const int lo = sq >= W ? sq - W + 1 : 0, hi = sq < H ? sq : H - 1;
-                if (valid_w && g < G && sq >= 0 && sq < S && o < a.cout && r >= lo && r <= hi) {
-                    const int bid = net * nout + g * a.cout + o;
-                    const long oi = ((long)n_w * nout + g * a.cout + o) * SKP + (long)(sq + XD_ROW0) * HP + r + XD_COL0;
-                    float v = (hs[(Q * 2 + 0) * 64] + hs[(Q * 2 + 1) * 64]) + a.bias[bid];
-                    if (a.act) { if (v < 0) v = v * act_p[bid]; }                 // cconv_dc_cuda.cu:360-362
-                    if (a.residual) v = v + res_p[oi];                           // fused TileAdd
-                    a.out[oi] = v;
-                }
-            });
-        }
-        XD_T(6);
-        if (!have_next) break;
-        cur = nxt;
-        voff = voff_n;
-        have_next = decode(kt + 2, nxt);
-        voff_n = have_next ? dma_lane_offset(nxt) : voff;
-    }
-    XD_WAIT0();
-#ifdef XD_STAMP
-    if (lane == 0) for (int i = 0; i < 10; ++i) xd_stamps[((blockIdx.x & 255) * 8 + ((blockIdx.x >> 8) & 1) * 4 + WV) * 10 + i] += st[i];
-#endif
-}
-
-__global__ __launch_bounds__(XT_THREADS, 3) void k_cconv16dt(XdArgs a) {
-    __shared__ __attribute__((aligned(16))) float ringA[2 * XD_STAGE_A];     // two weight images: 12 KB
-    __shared__ __attribute__((aligned(16))) float ringB[4 * 2 * XT_NU * 256];   // per wave: two stages x three 1 KB units of its own 16 rows: 24 KB
-    __shared__ float halo[(2 * 4 + 1) * XD_NHALO * 4];
-    __shared__ float hs[4 * XD_GB * 2 * 64];
-    for (int i = threadIdx.x; i < XD_NHALO * 4; i += XT_THREADS) halo[2 * 4 * XD_NHALO * 4 + i] = 0.f;
-    __syncthreads();
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    switch (wave) {
-        case 0: xt_body<0>(a, ringA, ringB, halo, hs, lane); break;
-        case 1: xt_body<1>(a, ringA, ringB, halo, hs, lane); break;
-        case 2: xt_body<2>(a, ringA, ringB, halo, hs, lane); break;
-        default: xt_body<3>(a, ringA, ringB, halo, hs, lane); break;
-    }
-}
-
-// Same contract as lic360_cconv16_dq_plane (returns 3 for batches that do not qualify).
-LIC360_API int lic360_cconv16_dt_plane(void *stream, const lic360_conv_plan *p, const float *x, const float *packed, const float *bias,
-                                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod) {
-    ARG_CHECK(p && conv16dc_ok(p) && x && packed && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n && h > 0 && h <= 64 && w > 0);
-    if (n % 8 || (n / nb) % 8 || x_mod != n) return 3;
-    const int G = p->ngroup, S = h + w - 1;
-    if (psum < 0 || psum >= h + w + G - 2) return 0;
-    int rows, pitch, row0, col0;
-    if (lic360_dc4_layout(h, w, &rows, &pitch, &row0, &col0)) return 2;
-    ARG_CHECK(row0 == XD_ROW0 && col0 == XD_COL0);
-    XdArgs a;
-    a.x = x; a.packed = packed; a.bias = bias; a.act = act; a.residual = residual; a.out = out;
-    a.G = G; a.cout = p->cout; a.hidden = p->constrain == 5 ? 0 : 1; a.H = h; a.W = w; a.npb = n / nb; a.x_mod = x_mod; a.N = n; a.psum = psum;
-    a.ngb_all = conv16dc_ngb(p); a.NKB = conv16dc_nkb(p); a.HP = pitch; a.SKP = (long)rows * pitch;
-    a.can_pair = 1; a.rs = 0;
-    int gb_lo = 1 << 30, gb_hi = -1;
-    for (int gb = 0; gb < a.ngb_all; ++gb) {
-        bool live = false;
-        for (int q = 0; q < XD_GB; ++q) {
-            const int g = gb * XD_GB + q, sq = psum - g;
-            live = live || (g < G && sq >= 0 && sq < S);
-        }
-        if (!live) continue;
-        if (gb < gb_lo) gb_lo = gb;
-        if (gb > gb_hi) gb_hi = gb;
-    }
-    if (gb_hi < 0) return 0;
-    a.gb_hi = gb_hi; a.n_gbv = gb_hi - gb_lo + 1;
-    ARG_CHECK(a.n_gbv <= 32);
-    static const int grid = [] { const char *e = getenv("LIC360_DT_GRID"); const int g = e ? atoi(e) : 0; return g >= 8 && g <= 4096 ? g : 768; }();
-    hipLaunchKernelGGL(k_cconv16dt, dim3(grid), dim3(XT_THREADS), 0, (hipStream_t)stream, a);
-    LAUNCH_CHECK();
-    return 0;
-}

@@ -41,7 +41,6 @@ struct lic360_codec {
     float *packed16dc[12];                     // weight layout of the decode-order 16x16x4 kernel (csrc/cconv16dc_kernels.hip), layers 1..11
     bool use16dc = false;                      // LIC360_DC=16 / q: hidden + last decode layers on the 16x16x4 kernel (opt-in; the default is the 4x4x1 kernel)
     bool use16dq = false;                      // LIC360_DC=q: its class-sequential 4-wave form where the batch qualifies
-    bool use16dt = false;                      // LIC360_DC=t: one 16-row column tile per wave, three workgroups per CU
     bool use4, use16, fuse_tables = true;      // fuse_tables: LIC360_EC_FUSE=0 keeps the separate table kernel (A/B runs)
     int dc_mode = 0;                           // A/B switches of the decode kernel, read from the environment once, at create
     int *e_ctr = nullptr;                      // 8 task counters of the encode kernel
@@ -644,8 +643,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     c->use16 = c->use4 && ec_mode == 16 && lic360_conv16_supported(c->plan[0]) && lic360_conv16_supported(c->plan[1]) && lic360_conv16_supported(c->plan[2]);
     { const char *fd = getenv("LIC360_DC");                           // decode order, hidden + last layers: "16" = the 16x16x4 MFMA kernel
       c->use16dq = fd && fd[0] == 'q';
-      c->use16dt = fd && fd[0] == 't';
-      c->use16dc = c->use4 && h <= 64 && (fd && ((fd[0] == '1' && fd[1] == '6') || fd[0] == 'q' || fd[0] == 't')) && lic360_conv16dc_supported(c->plan[1]) && lic360_conv16dc_supported(c->plan[2]); }
+      c->use16dc = c->use4 && h <= 64 && (fd && ((fd[0] == '1' && fd[1] == '6') || fd[0] == 'q')) && lic360_conv16dc_supported(c->plan[1]) && lic360_conv16dc_supported(c->plan[2]); }
     if (c->use16) { if (lic360_ec16_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else if (c->use4 && w >= 7 && ec_mode != 3) {
         if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
@@ -780,10 +778,6 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
         // hidden / last layers: the input-stationary 16x16x4 kernel, except in latency mode (few samples: the 4x4x1 kernel's
         // one-group tasks spread a plane over more workgroups)
         if (c->use16dc && layer >= 1 && (long)3 * B * ((G + 2) / 3) > 128) {
-            if (c->use16dt) {
-                const int rc = lic360_cconv16_dt_plane(stream, pl, xin, c->packed16dc[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
-                if (rc != 3) return rc;
-            }
             if (c->use16dq) {
                 const int rc = lic360_cconv16_dq_plane(stream, pl, xin, c->packed16dc[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
                 if (rc != 3) return rc;

@@ -220,10 +220,6 @@ int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *plan, const fl
  * lic360_cconv16_dc_plane then.  Replaces the same reference call (extension/cconv_dc_cuda.cu:313-398). */
 int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
                             const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
-/* ... and with ONE 16-row column tile per wave (96 accumulators, three independent 4-wave workgroups per CU): needs 8 | n, 8 | n / nb and
- * x_mod == n; returns 3 otherwise.  Same reference call (extension/cconv_dc_cuda.cu:313-398), same packed weights, same results. */
-int lic360_cconv16_dt_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
-                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
 
 /* Last layer of the latent entropy model with the CDF-table build fused into its epilogue (SURVEY.md §7 k_cconv_ec_last_gmm;
  * replaces the last CconvEcBatch.forward + TileExtractBatch + EntropyBatchGmmTable.forward_batch of

@@ -1023,16 +1023,6 @@ def test_cconv16_dq_planes_bit_exact(lic, case):
     _cconv16_dc_planes(lic, case, "lic360_cconv16_dq_plane")
 
 
-@pytest.mark.parametrize("case", [(48, 4, True, True, 3, 48, 8, 16), (48, 3, True, False, 3, 48, 64, 20), (12, 4, True, True, 1, 16, 64, 9),
-                                  (8, 4, True, True, 1, 48, 40, 12), (4, 3, True, False, 2, 96, 30, 6), (16, 4, True, True, 1, 8, 50, 30),
-                                  (8, 4, False, True, 3, 144, 33, 21), (8, 4, True, True, 1, 24, 17, 40)],
-                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
-def test_cconv16_dt_planes_bit_exact(lic, case):
-    """one 16-row column tile per wave (three 4-wave workgroups per CU): four quarters of a sample, two samples x two quarters, four
-    samples per task by the height of the block's window; 1, 2, 3 and 6 samples per net and XCD (idle slots), short and full diagonals"""
-    _cconv16_dc_planes(lic, case, "lic360_cconv16_dt_plane")
-
-
 def _cconv16_dc_planes(lic, case, entry):
     """lic360_cconv16_dc_plane (hidden / last layers of the latent nets in decode order: MFMA columns = input rows of one input
     anti-diagonal) on the lic360_dc4_layout: after every checked plane the persistent output equals the oracle's
