@@ -36,7 +36,9 @@ struct AcBitReader {
 struct AcState {
     uint32_t low, high, code;
     uint64_t underflow;
-    int error;         // 0 ok; 1 zero-frequency symbol; 2 range invariant; 3 decoder consistency
+    int error;         // 0 ok; 1 zero-frequency symbol; 2 range invariant; 3 decoder consistency (last writer wins in these host/device
+                       // functions).  The DEVICE ENCODER's serial core (k_ac_encode, codec_fused.hip) keeps a sticky BIT MASK instead: 1 | 2 = 3
+                       // there means "empty symbol and range fault", not the decoder's code 3; both read as "stream invalid" (non-zero)
 };
 
 AC_HD void ac_bw_init(AcBitWriter &w, uint8_t *buf, long cap) { w.buf = buf; w.cap = cap; w.len = 0; w.acc = 0; w.nacc = 0; }
