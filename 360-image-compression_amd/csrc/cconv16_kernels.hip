@@ -133,11 +133,51 @@ LIC360_API int lic360_ec16_layout(int h, int w, int *hp, int *wp) {
 #define C16_STR2(x) #x
 #define C16_STR(x) C16_STR2(x)
 #define C16_WAIT_PREV() asm volatile("s_waitcnt vmcnt(" C16_STR(C16_NDMA) ")" ::: "memory")   // all but the youngest step's DMAs
+#define C16_NDMA4 10                       // cin = 4: the four waves of set 0 issue the whole step image, 10 windows each
+#define C16_WAIT_PREV4() asm volatile("s_waitcnt vmcnt(" C16_STR(C16_NDMA4) ")" ::: "memory")
+// KIND: 0 = a window of x halo tiles, 1 = a window of packed weights (timing ablations C16_EXP_NOXDMA / NOWDMA / DMAADDR only)
+template <int KIND = 1>
 __device__ __forceinline__ void c16_dma_x4(const float *src, unsigned lds_byte_addr) {
 #ifdef C16_EXP_NODMA
     return;
 #endif
+#ifdef C16_EXP_NOXDMA
+    if (KIND == 0) return;
+#endif
+#ifdef C16_EXP_NOWDMA
+    if (KIND == 1) return;
+#endif
+#ifdef C16_EXP_DMAADDR                                                        // the address arithmetic without the instruction
+    asm volatile("" ::"v"(src), "s"(lds_byte_addr) : "memory");
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
+}
+// the form the kernels use: 64-bit UNIFORM base (SGPR pair) + 32-bit per-lane byte offset.  The per-lane offsets are loop-invariant registers and a
+// window's position goes into the scalar base, so a DMA costs scalar instructions only: with per-lane 64-bit pointers every DMA carried 2-8
+// VALU instructions (two quarter-rate multiplies for the x windows) into the MFMA stream -- stamps with the DMA instruction removed but its
+// address arithmetic kept ran as slowly as the full kernel (tools/ec_stamp.sh -DC16_EXP_DMAADDR).
+template <int KIND = 1>
+__device__ __forceinline__ void c16_dma_s(unsigned voff, const float *sbase, unsigned lds_byte_addr) {
+#ifdef C16_EXP_NODMA
+    return;
+#endif
+#ifdef C16_EXP_NOXDMA
+    if (KIND == 0) return;
+#endif
+#ifdef C16_EXP_NOWDMA
+    if (KIND == 1) return;
+#endif
+#ifdef C16_EXP_DMAADDR
+    asm volatile("" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+    return;
+#endif
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ const float *c16_uniform(const float *p) {     // the value IS wave-uniform; this tells the compiler
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const float *)(((unsigned long)hi << 32) | lo);
 }
 __device__ __forceinline__ unsigned c16_lds_addr(const float *p) {
     return (unsigned)(unsigned long)(__attribute__((address_space(3))) const float *)p;
@@ -157,6 +197,18 @@ struct C16Args {
     uint2 *rec;                                // [N][G*H*W] (cdf[sym], cdf[sym+1]) in coding order
 };
 
+#ifdef C16_STAMP
+// diagnostic build only (tools/ec_stamp.sh): cycles per phase of the hidden-layer instantiation, summed per wave over the launches
+__device__ unsigned long long c16_stamps[256 * 8 * 10];
+#define C16_T(i) do { if constexpr (CIN == 4 && !FUSE) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[i] += t_ - t0; t0 = t_; } } while (0)
+LIC360_API int lic360_c16_stamps(unsigned long long *host_out, int clear) {
+    if (host_out) HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(c16_stamps), sizeof(c16_stamps)));
+    if (clear) { static unsigned long long z[256 * 8 * 10]; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c16_stamps), z, sizeof(z))); }
+    return 0;
+}
+#else
+#define C16_T(i)
+#endif
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // taps of the three tap-diagonal ranges (d = kh + kw <= 3, 4..5, 6..8), in tap order
@@ -209,8 +261,76 @@ __device__ __forceinline__ void c16_range4(f32x4 (*acc)[25], const float *xs, co
     });
 }
 
-template <int CIN, int CLS, int PS, bool FUSE>
-__device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *comb, int *tq, const int tid, const int lane) {
+// FUSE: table build of a finished task -- all three nets' outputs of the task's tiles are in LDS (comb + C16_COMB): a thread per coded symbol builds
+// the 9-entry CDF (softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159) and writes the symbol's (cdf[sym], cdf[sym+1])
+// record at its place in coding order.  Two passes over the task's (tile, group, position) symbols: masked ones get their (0, 0) record at
+// once, the coded ones are COMPACTED into a list first (the partial-sum half of comb is dead here), so that the CDF arithmetic -- 9 % of the
+// kernel when every thread that owned a symbol ran it, masked or not, in lockstep with its wave -- runs on dense waves.
+// NOT inlined: one copy of its ~10 KB of code in the kernel instead of one per call site and lane class (instruction cache, see c16_body).
+typedef __attribute__((address_space(3))) float c16_lds_f;
+typedef __attribute__((address_space(3))) int c16_lds_i;
+template <int GPB, int TPT>
+__device__ __attribute__((noinline)) void c16_tables_phase(c16_lds_f *comb, int tid, int tb_T, int tb_nt, int tb_n, int tb_gb, const float *__restrict__ mask,
+                                                           const float *__restrict__ code, uint2 *__restrict__ rec, const int *__restrict__ pidx,
+                                                           const int *__restrict__ plane_start, int ntx, int H, int W, int G) {
+    c16_lds_i *const tl = (c16_lds_i *)comb;                               // [0, 64 GPB TPT): item list, then the counter
+    c16_lds_i *const tcnt = tl + 64 * GPB * TPT;
+    __syncthreads();                                                        // the last tile's y is complete, its partial sums have been read
+    if (tid == 0) *tcnt = 0;
+    __syncthreads();
+    const long HW = (long)H * W;
+    auto locate = [&](int item, int &g, int &th, int &tw, int &pos, int &tt, int &q) __attribute__((always_inline)) {
+        tt = item / (64 * GPB);
+        const int w = item - tt * (64 * GPB);
+        q = w >> 6; pos = w & 63;
+        const int T = tb_T + tt, ty = T / ntx, tx = T - ty * ntx;
+        th = ty * C16_TH + (pos >> 4); tw = tx * C16_TW + (pos & 15); g = tb_gb * GPB + q;
+    };
+    auto record_at = [&](int g, int th, int tw) __attribute__((always_inline)) -> long {      // the symbol's place in coding order (tile_extract_cuda.cu:36-41)
+        const int sd = th + tw, p = sd + g, la = p >= G ? p - G + 1 : 0;
+        return (long)tb_n * G * HW + plane_start[p] + (pidx[sd] - pidx[la]) + (th - (sd >= W ? sd - W + 1 : 0));
+    };
+    for (int item = tid; item < tb_nt * 64 * GPB; item += C16_THREADS) {
+        int g, th, tw, pos, tt, q;
+        locate(item, g, th, tw, pos, tt, q);
+        if (g < G && th < H && tw < W) {
+            if (mask[(((long)tb_n * G + g) * H + th) * W + tw] < 0.5f) rec[record_at(g, th, tw)] = make_uint2(0u, 0u);   // coder.cpp:79
+            else tl[__hip_atomic_fetch_add(tcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = item;
+        }
+    }
+    __syncthreads();
+    const int ncoded = *tcnt;
+    for (int t = tid; t < ncoded; t += C16_THREADS) {
+        int g, th, tw, pos, tt, q;
+        locate(tl[t], g, th, tw, pos, tt, q);
+        float v[9];
+#pragma unroll
+        for (int net = 0; net < 3; ++net)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + (((tt * 3 + net) * GPB + q) * 3 + c) * 64 + pos];
+        int Tb[9];
+#ifdef C16_EXP_NOTAB                                                          // ablation (timing only): what the CDF arithmetic of the table phase costs
+        for (int e = 0; e < 9; ++e) Tb[e] = (int)v[e];
+#else
+        gmm_cdf9(v, v + 3, v + 6, Tb);                                      // softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159
+#endif
+        int sym = (int)code[(((long)tb_n * G + g) * H + th) * W + tw];
+        sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
+        rec[record_at(g, th, tw)] = make_uint2((unsigned)Tb[sym], (unsigned)Tb[sym + 1]);
+    }
+    __syncthreads();                                                        // (the list lies where the next tile's partial sums go)
+}
+
+// PS (the wave's pair of tile rows): compile-time (PS_T >= 0) in the unfused kernels, a RUN-TIME value in the fused one (four copies of this
+// code instead of eight).  With eight copies a kernel is 72-96 KB of code, every wave looping over ~12 KB of its own -- more than the 64 KB
+// instruction cache two CUs share: SQC_ICACHE_MISSES 4.2 M + 3.8 M duplicates per hidden-layer launch, ~4.6 per wave and tile, all in the
+// once-per-tile code (tree, epilogue, task set-up); 11 M + 4.6 M for the fused kernel, which was 250 KB with the table phase inlined at two
+// sites of eight copies.  Measured (round 4, same box): the run-time form removes the misses (14 K per launch) and costs the hidden layer
+// +0.7 % and the first layer +4 % (their DMA window selection becomes scalar branches), so only the fused kernel keeps it -- there, with the
+// table phase as ONE noinline function (63 KB in all), it is part of a 6 % gain (see DMA0 below).
+template <int CIN, int CLS, bool FUSE, int PS_T = -1>
+__device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *comb, int *tq, const int tid, const int lane, const int ps_rt) {
+    const int PS = PS_T >= 0 ? PS_T : ps_rt;
     static_assert(!FUSE || CIN == 4, "the fused table build belongs to the last (cin = 4) layer");
     constexpr int NSUB = FUSE ? 3 : 1;                                      // FUSE: the 3 stacked nets of an image, one after the other per tile
     constexpr int GPB = FUSE ? C16_FGPB : 4, RPG = FUSE ? 3 : 4;            // groups per block, MFMA rows per group (row = RPG q + r)
@@ -221,12 +341,16 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     constexpr int TPT = FUSE ? C16_FTPT : C16_TPT;
     constexpr int NA = NAcc<CIN>::value;
     constexpr int TCS = CIN == 4 ? 4 : 16;                                  // input groups per step
-    constexpr int WAVE = PS * 4 + CLS;
+    const int WAVE = PS * 4 + CLS;
     const int G = a.G, C = G * CIN, nout = G * a.cout;
     const long PL = (long)a.hp * a.wp;
     const int xcd = blockIdx.x & 7;
     const int ns_x = (a.N - xcd + 7) >> 3;                                  // samples of this XCD: n = xcd + 8 m
     const int n_my = ns_x * a.n_chunks * a.n_gb;
+#ifdef C16_STAMP
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_entry = t0;
+#endif
     // ---- task queue: thread 0 pulls task numbers four tasks ahead of the compute cursor into an 8-slot LDS ring
     // (the issue cursor runs two steps ahead: with one-step tasks it reads task c + 3 while the compute cursor is in task c,
     // and a barrier must lie between a pull and its first read)
@@ -259,11 +383,28 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     // both re-fetch a valid quad); a weight window moves 1 KB of the step's packed weights
     constexpr int QPR = C16_HC / 4, QPP = C16_PLANE / 4;                    // quads per row / per plane incl. pad (5, 41)
     static_assert(C16_XWIN * 64 >= 16 * QPP && C16_XWIN + C16_WWIN + 1 == 8 * C16_NDMA, "DMA windows cover the step image");
-    constexpr int NXD = (C16_XWIN - WAVE + 7) / 8;                          // x windows of this wave (1 or 2)
+    // DMA0 (fused kernel): ONLY the waves of set 0 issue DMAs -- window j = CLS + 4 m, m < 10; set 1 runs no issue cursor.  Set 0 (older waves: they
+    // win the SIMD's issue arbitration) reaches the step barrier ~1000 cycles before set 1 (tools/ec_stamp.sh), so the DMA issue costs the
+    // workgroup less there.  Where the 40 DMAs of a step are issued was measured per kernel (tools/ec_variants.sh, same box; ms per 48 images):
+    //   five per wave in both sets, between the chains of range 0 (round 2/3):   hidden 12.37   fused 12.05
+    //   ten per wave of set 0, behind the step's MFMAs (barrier wait):           hidden 12.42   fused 11.80
+    //   ten per wave of set 0, one behind each chain of range 0 (SPREAD):        hidden 12.97   fused 11.32
+    // (the cost of the DMAs -- ~1 ms per launch, NODMA ablation -- moves between the sets but is conserved in the hidden layers).
+    constexpr bool DMA0 = FUSE;
+#ifdef C16_DMA_SPREAD
+    constexpr bool SPREAD = DMA0 && (C16_DMA_SPREAD != 0);
+#else
+    constexpr bool SPREAD = DMA0;
+#endif
+    constexpr int NDW = DMA0 ? C16_NDMA4 : C16_NDMA;                        // DMAs per issuing wave and step
+    const bool issuer = !DMA0 || PS == 0;
+    constexpr int NXD = DMA0 ? 3 : (PS_T >= 0 ? (C16_XWIN - (PS_T * 4 + CLS) + 7) / 8 : 2);   // x windows of a wave (j < 11)
+    auto window = [&](int m) __attribute__((always_inline)) { return DMA0 ? CLS + 4 * m : WAVE + 8 * m; };
     int xpl[NXD], xg[NXD];
+    unsigned xoff[NXD];
 #pragma unroll
     for (int m = 0; m < NXD; ++m) {
-        int e = (WAVE + 8 * m) * 64 + lane;
+        int e = window(m) * 64 + lane;
         if (e >= 16 * QPP) e = 0;
         const int slot = e / QPP;
         int rem = e - slot * QPP;
@@ -271,7 +412,10 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         const int row = rem / QPR, cq = rem - row * QPR;
         xpl[m] = CIN == 4 ? slot : ((slot & 3) * 4 + (slot >> 2));          // cin = 1: slot 4 k + sq holds channel tc0 + 4 sq + k
         xg[m] = row * a.wp + cq * 4;
+        xoff[m] = (unsigned)(((long)xpl[m] * PL + xg[m]) * 4);              // byte offset from the step's first plane at the tile origin
     }
+    const unsigned woff = lane * 16;
+    const bool ragged = C % (TCS * CIN) != 0;                               // the last step holds fewer than 16 planes
     const unsigned lds_base = c16_lds_addr(lds);
     // ---- issue cursor
     int iq = 0, itile = 0, istep = 0, inet = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;
@@ -295,15 +439,32 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     // LDS-DMA m (of 5) of the issue cursor's step into buffer `buf`; issue_advance() then moves the cursor (an exhausted cursor
     // keeps re-reading its last addresses: every DMA stays unconditional and inside the tensors, 5 per wave and step)
     auto issue_dma = [&](auto mm, int buf) __attribute__((always_inline)) {
-        constexpr int m = decltype(mm)::value, j = WAVE + 8 * m;
+        constexpr int m = decltype(mm)::value;
+        const int j = window(m);
         const unsigned lb = lds_base + (unsigned)buf * (C16_BUF * 4);
-        const float *wsrc = iwb + (long)istep * C16_WFL + lane * 4;
-        if constexpr (j < C16_XWIN) {
-            int c = istep * (TCS * CIN) + xpl[m];
-            if (c > C - 1) c = C - 1;                                       // planes past the last channel only meet zero weights
-            c16_dma_x4(ixb + (long)c * PL + xg[m], lb + j * 1024);
-        } else if constexpr (j < C16_XWIN + C16_WWIN) c16_dma_x4(wsrc + (j - C16_XWIN) * 256, lb + j * 1024);
-        else c16_dma_x4(wsrc, lb + j * 1024);                               // the 40th window: dump
+        if constexpr (!DMA0) {
+            // per-lane 64-bit addresses.  (The scalar-base form below was measured here too: hidden layers 12.76 against 12.40 ms -- the
+            // base arithmetic of 5 DMAs per wave lands in the scalar unit between the chains of range 0 and spills more SGPRs.)
+            const float *wsrc = iwb + (long)istep * C16_WFL + lane * 4;
+            if (m < NXD && j < C16_XWIN) {
+                constexpr int mx = m < NXD ? m : 0;
+                int c = istep * (TCS * CIN) + xpl[mx];
+                if (c > C - 1) c = C - 1;                                   // planes past the last channel only meet zero weights
+                c16_dma_x4<0>(ixb + (long)c * PL + xg[mx], lb + j * 1024);
+            } else c16_dma_x4(wsrc + (j < C16_XWIN + C16_WWIN ? (j - C16_XWIN) * 256 : 0), lb + j * 1024);   // weights; the 40th window: dump
+            return;
+        }
+        const float *wsrc = iwb + (long)istep * C16_WFL;
+        if (m < NXD && j < C16_XWIN) {                                      // (uniform)
+            constexpr int mx = m < NXD ? m : 0;
+            const int c0 = istep * (TCS * CIN);
+            unsigned vo = xoff[mx];
+            if (ragged && c0 + TCS * CIN > C) {                             // planes past the last channel only meet zero weights: re-read the last one
+                const int c = c0 + xpl[mx] > C - 1 ? C - 1 - c0 : xpl[mx];
+                vo = (unsigned)(((long)c * PL + xg[mx]) * 4);
+            }
+            c16_dma_s<0>(vo, c16_uniform(ixb + (long)c0 * PL), lb + j * 1024);
+        } else c16_dma_s(woff, c16_uniform(wsrc + (j < C16_XWIN + C16_WWIN ? (j - C16_XWIN) * 256 : 0)), lb + j * 1024);   // weights; the 40th window: dump
     };
     auto issue_advance = [&]() __attribute__((always_inline)) {
         if (ivalid) {
@@ -333,14 +494,16 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
-        static_for<C16_NDMA>([&](auto mm) { issue_dma(mm, buf); });
+        static_for<NDW>([&](auto mm) { issue_dma(mm, buf); });
         issue_advance();
     };
-    issue_task();
-    if (!ivalid) return;                                                    // uniform: the whole workgroup has no task
-    issue_tile();
-    issue(0);
-    issue(1);
+    if (task(0) >= n_my) return;                                            // uniform: the whole workgroup has no task
+    if (issuer) {
+        issue_task();
+        issue_tile();
+        issue(0);
+        issue(1);
+    }
     // ---- compute cursor
     int cq = 0, ctile = 0, cstep = 0, cnet = 0, c_nsteps, c_tile0, c_n, c_gb;
     decode(task(0), c_n, c_tile0, c_gb);
@@ -356,7 +519,8 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     // operand addresses: lane (k = l >> 4, j = l & 15) reads plane slot 4 k + {gid | sq}, row 2 PS + t + kh, column j + kw
     const int xlane = (lane >> 4) * 4 * C16_PLANE + (C16_NT * PS) * C16_HC + (lane & 15);
     const int wlane = C16_XFL + CLS * C16_SLOTS * 64 + lane;
-    C16_WAIT_PREV();
+    if constexpr (DMA0) C16_WAIT_PREV4();
+    else C16_WAIT_PREV();
     __syncthreads();
     float e_bias[2] = {0.f, 0.f}, e_act[2] = {0.f, 0.f}, e_res[2] = {0.f, 0.f};
     long e_oi[2] = {0, 0};
@@ -367,63 +531,14 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     bool tb_pending = false;
     int tb_T = 0, tb_nt = 0, tb_n = 0, tb_gb = 0;                           // first tile and tile count of the finished task
     auto tables = [&]() __attribute__((always_inline)) {
-        // all three nets of the task's tiles are in LDS: a thread per coded symbol builds the 9-entry CDF (softmax, sigma floor, erf CDF,
-        // fix-up: entropy_gmm_table_cuda.cu:29-107,138-159) and writes the symbol's (cdf[sym], cdf[sym+1]) record at its place in coding order
-        // Two passes over the task's (tile, group, position) symbols: masked ones get their (0, 0) record at once, the coded ones are
-        // COMPACTED into a list first (the partial-sum half of comb is dead here), so that the CDF arithmetic -- 9 % of the kernel when
-        // every thread that owned a symbol ran it, masked or not, in lockstep with its wave -- runs on dense waves.
-        int *const tl = (int *)comb;                                        // [0, 64 GPB TPT): item list, then the counter
-        int *const tcnt = tl + 64 * GPB * TPT;
-        __syncthreads();                                                    // the last tile's y is complete, its partial sums have been read
-        if (tid == 0) *tcnt = 0;
-        __syncthreads();
-        const long HW = (long)a.H * a.W;
-        auto locate = [&](int item, int &g, int &th, int &tw, int &pos, int &tt, int &q) __attribute__((always_inline)) {
-            tt = item / (64 * GPB);
-            const int w = item - tt * (64 * GPB);
-            q = w >> 6; pos = w & 63;
-            const int T = tb_T + tt, ty = T / a.ntx, tx = T - ty * a.ntx;
-            th = ty * C16_TH + (pos >> 4); tw = tx * C16_TW + (pos & 15); g = tb_gb * GPB + q;
-        };
-        auto record_at = [&](int g, int th, int tw) __attribute__((always_inline)) -> long {      // the symbol's place in coding order (tile_extract_cuda.cu:36-41)
-            const int sd = th + tw, p = sd + g, la = p >= G ? p - G + 1 : 0;
-            return (long)tb_n * G * HW + a.plane_start[p] + (a.pidx[sd] - a.pidx[la]) + (th - (sd >= a.W ? sd - a.W + 1 : 0));
-        };
-        for (int item = tid; item < tb_nt * 64 * GPB; item += C16_THREADS) {
-            int g, th, tw, pos, tt, q;
-            locate(item, g, th, tw, pos, tt, q);
-            if (g < G && th < a.H && tw < a.W) {
-                if (a.mask[(((long)tb_n * G + g) * a.H + th) * a.W + tw] < 0.5f) a.rec[record_at(g, th, tw)] = make_uint2(0u, 0u);   // coder.cpp:79
-                else tl[atomicAdd(tcnt, 1)] = item;
-            }
-        }
-        __syncthreads();
-        const int ncoded = *tcnt;
-        for (int t = tid; t < ncoded; t += C16_THREADS) {
-            int g, th, tw, pos, tt, q;
-            locate(tl[t], g, th, tw, pos, tt, q);
-            float v[9];
-#pragma unroll
-            for (int net = 0; net < 3; ++net)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + (((tt * 3 + net) * GPB + q) * 3 + c) * 64 + pos];
-            int Tb[9];
-#ifdef C16_EXP_NOTAB                                                          // ablation (timing only): what the CDF arithmetic of the table phase costs
-            for (int e = 0; e < 9; ++e) Tb[e] = (int)v[e];
-#else
-            gmm_cdf9(v, v + 3, v + 6, Tb);                                  // softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159
-#endif
-            int sym = (int)a.code[(((long)tb_n * G + g) * a.H + th) * a.W + tw];
-            sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
-            a.rec[record_at(g, th, tw)] = make_uint2((unsigned)Tb[sym], (unsigned)Tb[sym + 1]);
-        }
-        __syncthreads();                                                    // (the list lies where the next tile's partial sums go)
+        c16_tables_phase<GPB, TPT>((c16_lds_f *)comb, tid, tb_T, tb_nt, tb_n, tb_gb, a.mask, a.code, a.rec, a.pidx, a.plane_start, a.ntx, a.H, a.W, G);
         tb_pending = false;
     };
     // (comb is double-buffered by tile parity: with one-step tiles the next tile's partial sums are written before the
     // barrier that would separate them from this tile's reads)
     int cur = 0, ntile = 0;                                                 // cur: LDS buffer of the step being computed
     bool done = false;
+    C16_T(8);
     do {
         const float *xs = lds + cur * C16_BUF + xlane, *ws = lds + cur * C16_BUF + wlane;
         const int nbuf = cur >= 1 ? cur - 1 : C16_NBUF - 1;                  // DMAs of the step after next go to (cur + 2) mod 3
@@ -455,21 +570,26 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 }
             }
         }
+        C16_T(0);
         if constexpr (CIN == 4) {
             // chains in three ranges of tap diagonals (d <= 3, 4..5, 6..8): the later ranges die first as tc grows
             C16Ops ops[C16_PF + 1];
             static_for<C16_PF>([&](auto ii) { c16_load4<CLS, c16_range_tap(0, decltype(ii)::value)>(ops[decltype(ii)::value], xs, ws); });
             // the step's 5 DMAs are issued between the chains of range 0 (one after every second chain): issued together at the
             // top of the step they keep both waves of a SIMD off the matrix pipe for their whole issue time
+            auto nohook = [](auto) __attribute__((always_inline)) {};
+            // SPREAD: set 0's ten DMAs go between the ten chains of range 0 (one each) instead of behind the step's MFMAs
             auto dmahook = [&](auto ii) __attribute__((always_inline)) {
                 constexpr int i = decltype(ii)::value;
-                if constexpr ((i & 1) == 0 && i / 2 < C16_NDMA) issue_dma(IC<i / 2>{}, nbuf);
+                if constexpr (SPREAD && i < NDW) { if (PS == 0) issue_dma(IC<i>{}, nbuf); }
+                // not DMA0: every wave issues its five windows here, one after every second chain (issued together at the top of the step they
+                // keep both waves of a SIMD off the matrix pipe for their whole issue time)
+                else if constexpr (!DMA0 && (i & 1) == 0 && i / 2 < C16_NDMA) issue_dma(IC<i / 2>{}, nbuf);
             };
-            auto nohook = [](auto) __attribute__((always_inline)) {};
             if (cstep == 0) {                                               // every chain starts here (dead ones on zero weights): no zeroing pass
                 if constexpr (FUSE) { if (tb_pending) tables(); }
                 c16_range4<CLS, 0, true>(acc, xs, ws, ops, true, dmahook);
-                issue_advance();
+                if constexpr (!DMA0) issue_advance();
                 c16_range4<CLS, 1, true>(acc, xs, ws, ops, true, nohook);
                 c16_range4<CLS, 2, true>(acc, xs, ws, ops, false, nohook);
             } else {
@@ -481,7 +601,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 }
 #endif
                 c16_range4<CLS, 0, false>(acc, xs, ws, ops, dl > 4, dmahook);
-                issue_advance();
+                if constexpr (!DMA0) issue_advance();
                 if (dl > 4) c16_range4<CLS, 1, false>(acc, xs, ws, ops, dl > 6, nohook);
                 if (dl > 6) c16_range4<CLS, 2, false>(acc, xs, ws, ops, false, nohook);
             }
@@ -506,6 +626,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 });
             });
         }
+        C16_T(1);
 #ifdef C16_EXP_NOEPI
         if (last && c_n < 0) {
 #else
@@ -522,20 +643,35 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 }
             }
         }
-        C16_WAIT_PREV();                                                    // own DMAs of the NEXT step (issued a step ago) have landed
+        C16_T(2);
+        if constexpr (DMA0) {
+            if (PS == 0) {
+                // the tile's epilogue operands (ordinary loads, issued at the top of this step) are waited for HERE by the compiler -- not behind the
+                // DMAs below, which it cannot see: its vmcnt for them after the barrier would count the just-issued DMAs as well
+                if (last) asm volatile("" : "+v"(e_bias[0]), "+v"(e_bias[1]), "+v"(e_act[0]), "+v"(e_act[1]), "+v"(e_res[0]), "+v"(e_res[1]));
+                if constexpr (SPREAD) issue_advance();                      // (the step's windows went out between the chains of range 0)
+                else issue(nbuf);                                           // the step after next: 10 windows, then the cursor moves
+                C16_WAIT_PREV4();                                           // the NEXT step's windows (issued a step ago) have landed
+            }
+        } else C16_WAIT_PREV();                                             // own DMAs of the NEXT step (issued a step ago) have landed
+        C16_T(3);
 #ifdef C16_EXP_NOBAR
         if (last)
 #endif
         __syncthreads();
+        C16_T(4);
+#ifdef C16_STAMP
+        st[6] += 1; st[7] += last;
+#endif
         if (last) {
             // wave w finishes tile row w >> 1, output channels 2 (w & 1), 2 (w & 1) + 1 of the four groups: (F0 + F2) + (F1 + F3)
-            constexpr int trow = WAVE >> 1;
+            const int trow = WAVE >> 1;
 #ifdef C16_EXP_NOEPI
             if (c_n < 0)
 #endif
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                constexpr int rbase = 2 * (WAVE & 1);
+                const int rbase = 2 * (WAVE & 1);
                 const int r = rbase + rr;
                 const float *cb = comb + (FUSE ? 0 : (ntile & 1)) * C16_COMB + ((trow * 4) * 4 + r) * 64 + lane;
                 const float f0 = cb[0], f1 = cb[4 * 64], f2 = cb[8 * 64], f3 = cb[12 * 64];
@@ -571,9 +707,16 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
             }
         } else ++cstep;
         cur = cur + 1 == C16_NBUF ? 0 : cur + 1;
+        C16_T(5);
     } while (!done);
     if constexpr (FUSE) { if (tb_pending) tables(); }
     C16_WAIT0();                                                            // no DMA may outlive the workgroup's LDS
+#ifdef C16_STAMP
+    if constexpr (CIN == 4 && !FUSE) {
+        st[9] = __builtin_amdgcn_s_memtime() - t_entry;
+        if (lane == 0) for (int i = 0; i < 10; ++i) c16_stamps[((blockIdx.x & 255) * 8 + WAVE) * 10 + i] += st[i];
+    }
+#endif
 }
 
 template <int CIN, bool FUSE>
@@ -586,15 +729,25 @@ __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
 #ifdef C16_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);                           // (experiment) static priority for the younger wave of every SIMD
 #endif
-    switch (wave) {
-        case 0: c16_body<CIN, 0, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
-        case 1: c16_body<CIN, 1, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
-        case 2: c16_body<CIN, 2, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
-        case 3: c16_body<CIN, 3, 0, FUSE>(a, lds, comb, tq, tid, lane); break;
-        case 4: c16_body<CIN, 0, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
-        case 5: c16_body<CIN, 1, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
-        case 6: c16_body<CIN, 2, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
-        default: c16_body<CIN, 3, 1, FUSE>(a, lds, comb, tq, tid, lane); break;
+    const int ps = wave >> 2;
+    if constexpr (!FUSE) {
+        switch (wave) {
+            case 0: c16_body<CIN, 0, FUSE, 0>(a, lds, comb, tq, tid, lane, 0); break;
+            case 1: c16_body<CIN, 1, FUSE, 0>(a, lds, comb, tq, tid, lane, 0); break;
+            case 2: c16_body<CIN, 2, FUSE, 0>(a, lds, comb, tq, tid, lane, 0); break;
+            case 3: c16_body<CIN, 3, FUSE, 0>(a, lds, comb, tq, tid, lane, 0); break;
+            case 4: c16_body<CIN, 0, FUSE, 1>(a, lds, comb, tq, tid, lane, 1); break;
+            case 5: c16_body<CIN, 1, FUSE, 1>(a, lds, comb, tq, tid, lane, 1); break;
+            case 6: c16_body<CIN, 2, FUSE, 1>(a, lds, comb, tq, tid, lane, 1); break;
+            default: c16_body<CIN, 3, FUSE, 1>(a, lds, comb, tq, tid, lane, 1); break;
+        }
+    } else {
+        switch (wave & 3) {
+            case 0: c16_body<CIN, 0, FUSE>(a, lds, comb, tq, tid, lane, ps); break;
+            case 1: c16_body<CIN, 1, FUSE>(a, lds, comb, tq, tid, lane, ps); break;
+            case 2: c16_body<CIN, 2, FUSE>(a, lds, comb, tq, tid, lane, ps); break;
+            default: c16_body<CIN, 3, FUSE>(a, lds, comb, tq, tid, lane, ps); break;
+        }
     }
 }
 

@@ -16,3 +16,25 @@ fc.profile(True)
 fc.encode_async(code, mask); torch.cuda.synchronize()
 for k, (ms, n) in fc.profile_read().items():
     if n: print("%-12s %4d launches  %.4f ms each" % (k, n, ms / n))
+# diagnostic build (-DC16_STAMP, tools/ec_stamp.sh): cycles per phase and wave of the hidden-layer kernel, summed over one encode's 10 launches
+import ctypes as C
+import lic360 as lic
+try:
+    fn = lic._lib.lic360_c16_stamps
+except AttributeError:
+    fn = None
+if fn is not None:
+    fn.argtypes = [C.c_void_p, C.c_int]
+    fn(None, 1)
+    fc.encode_async(code, mask); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * (256 * 8 * 10))()
+    fn(buf, 0)
+    st = np.array(buf, dtype=np.float64).reshape(256, 8, 10) / 10.0      # per hidden-layer launch
+    names = ["step top", "ranges", "tree", "dma wait", "barrier", "post", "steps", "tiles", "preamble", "total"]
+    m = st.mean((0, 1))
+    print("cycles per wave and launch (mean over 256 workgroups x 8 waves):")
+    for i, nme in enumerate(names): print("  %-9s %12.0f  %5.1f %%" % (nme, m[i], 100 * m[i] / m[9] if i not in (6, 7) else 0))
+    print("  per step: ranges %.0f  top %.0f  wait %.0f  barrier %.0f  post %.0f ; per tile: tree %.0f  steps/tile %.2f" % (
+        m[1] / m[6], m[0] / m[6], m[3] / m[6], m[4] / m[6], m[5] / m[6], m[2] / m[7], m[6] / m[7]))
+    print("  total per workgroup: min %.0f  mean %.0f  max %.0f" % (st[:, :, 9].mean(1).min(), st[:, :, 9].mean(), st[:, :, 9].mean(1).max()))
+    for wv in range(8): print("  wave %d (ps %d, class %d): " % (wv, wv >> 2, wv & 3) + " ".join("%10.0f" % v for v in st[:, wv, :].mean(0)))
