@@ -43,7 +43,13 @@ static inline bool conv4_ok(const lic360_conv_plan *p) {
 // (cin = 4: tap = i, gid = (c - tap) mod 4;  cin = 1: tap = c + 4*i), r = output channel within the group.
 // A wave reads its class as two 64-float registers: lane (i%16)*4 + r of register i/16 holds the weight of leaf i, row r --
 // exactly the 4-lane block that `abid = i%16` selects for broadcast (cbsz = 4) in v_mfma_f32_4x4x1_16b_f32.
-__global__ void k_conv4_pack(const float *__restrict__ weight, float *__restrict__ packed, int nb, int ngroup, int cin, int cout, int hidden) {
+// QUAD part (read by the v6 kernels, cconv4v6_dc.inc): the same weights with the registers a wave needs for one DOUBLE step adjacent per lane, so
+// that it fetches them with one (cin = 4) or two (cin = 1) 16-byte loads instead of four / eight 4-byte ones -- the CU's address unit takes a wave
+// instruction at a time whatever its width, and the decode kernel's twelve waves kept it busy 864 of a double step's ~2900 cycles:
+//   quads[net][g][blk][c][lane][4]   cin = 4: blk = tc / 2, word = 2 (tc & 1) + register;   cin = 1: blk = tc / 4, word = tc & 3 (register 0 only)
+// wblk 4 KB blocks per output group (zero-filled past the last input group).
+__global__ void k_conv4_pack(const float *__restrict__ weight, float *__restrict__ packed, float *__restrict__ quads, int wblk, int nb, int ngroup, int cin,
+                             int cout, int hidden) {
     const long per_net = (long)ngroup * ngroup * C4_WSLOTS * 4, total = per_net * nb;
     const int C = ngroup * cin, nout = ngroup * cout;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -59,18 +65,28 @@ __global__ void k_conv4_pack(const float *__restrict__ weight, float *__restrict
             if (tc < L) v = weight[(((long)b * nout + g * cout + r) * C + tc * cin + gid) * 25 + tap];
         }
         packed[i] = v;
+        const long qb = (long)(b * ngroup + g) * wblk;
+        const int ln = (leaf & 15) * 4 + r;
+        if (cin == 4) quads[(qb + (tc >> 1)) * 1024 + c * 256 + ln * 4 + (tc & 1) * 2 + (leaf >> 4)] = v;
+        else if (leaf < 16) quads[(qb + (tc >> 2)) * 1024 + c * 256 + ln * 4 + (tc & 3)] = v;
     }
 }
 
 LIC360_API int lic360_conv4_supported(const lic360_conv_plan *p) { return p && conv4_ok(p) ? 1 : 0; }
+// a packed4 buffer of nb nets = [nb x slot part (ngroup^2 x 512 floats per net)][nb x quad part (ngroup x wblk x 1024 floats per net)]
+static inline long conv4_slot_floats(const lic360_conv_plan *p) { return (long)p->ngroup * p->ngroup * C4_WSLOTS * 4; }
+static inline int conv4_wblk(const lic360_conv_plan *p) { return p->cin == 4 ? (p->ngroup + 1) / 2 : 2 * ((p->ngroup + 7) / 8); }
+static inline long conv4_quad_floats(const lic360_conv_plan *p) { return (long)p->ngroup * conv4_wblk(p) * 1024; }
 LIC360_API long lic360_conv4_packed_floats(const lic360_conv_plan *p) {
-    return p && conv4_ok(p) ? (long)p->ngroup * p->ngroup * C4_WSLOTS * 4 : 0;
+    return p && conv4_ok(p) ? conv4_slot_floats(p) + conv4_quad_floats(p) : 0;
 }
 LIC360_API int lic360_conv4_pack(void *stream, const lic360_conv_plan *p, const float *weight, int nb, float *packed) {
     ARG_CHECK(p && conv4_ok(p) && weight && packed && nb > 0);
-    long total = lic360_conv4_packed_floats(p) * nb;
-    hipLaunchKernelGGL(k_conv4_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, nb, p->ngroup, p->cin,
-                       p->cout, p->constrain == 5 ? 0 : 1);
+    const long total = conv4_slot_floats(p) * nb;
+    float *quads = packed + total;
+    HIP_TRY(hipMemsetAsync(quads, 0, (size_t)conv4_quad_floats(p) * nb * sizeof(float), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_conv4_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, quads, conv4_wblk(p), nb, p->ngroup,
+                       p->cin, p->cout, p->constrain == 5 ? 0 : 1);
     LAUNCH_CHECK();
     return 0;
 }

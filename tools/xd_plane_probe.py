@@ -56,7 +56,22 @@ for p in planes:
     if has_stamps and os.environ.get("XWAVES"):
         for wv in range(8):
             line += "\n      wave (half %d, class %d): " % (wv >> 2, wv & 3) + " ".join("%7.0f" % v for v in st[:, wv, :].mean(0))
+    has6 = hasattr(L, "lic360_dc6_stamps")
+    if has6:
+        L.lic360_dc6_stamps.argtypes = [C.c_void_p, C.c_int]; L.lic360_dc6_stamps(None, 1)
     t4 = run(L.lic360_cconv4_dc_plane, packed4, p)
     print(line + "   | old %7.1f us" % t4)
+    if has6:                                                 # -DDC6_STAMP build (tools/dc6_stamp.sh): the 4x4x1 kernel's cycles per phase and wave
+        buf = (C.c_ulonglong * (256 * 12 * 10))()
+        L.lic360_dc6_stamps(buf, 0)
+        st = np.array(buf, dtype=np.float64).reshape(256, 12, 10) / 23.0
+        m = st.mean((0, 1))
+        names = ["task switch", "barrier", "half 0", "x issue", "half 1", "weights", "dsteps", "tasks", "lds write", "total"]
+        print("   4x4x1 kernel, cycles per wave and launch: " + "  ".join("%s %.0f" % (n, v) for n, v in zip(names, m)))
+        print("   per double step: switch %.0f  barrier %.0f  half0 %.0f  lds write %.0f  x issue %.0f  half1 %.0f  weights %.0f  (sum %.0f); per task: switch %.0f, %.1f double steps; workgroup totals min %.0f mean %.0f max %.0f" % (
+            m[0] / m[6], m[1] / m[6], m[2] / m[6], m[8] / m[6], m[3] / m[6], m[4] / m[6], m[5] / m[6], (m[:6].sum() + m[8]) / m[6], m[0] / max(m[7], 1), m[6] / max(m[7], 1),
+            st[:, :, 9].mean(1).min(), st[:, :, 9].mean(), st[:, :, 9].mean(1).max()))
+        if os.environ.get("XWAVES"):
+            for wv in range(12): print("      wave (set %d, class %d): " % (wv >> 2, wv & 3) + " ".join("%8.0f" % v for v in st[:, wv, :].mean(0)))
     tot16 += t16; tot4 += t4
 print("mean over planes: new %.1f us, old %.1f us" % (tot16 / len(planes), tot4 / len(planes)))
