@@ -182,6 +182,10 @@ int lic360_ec6_layout(int h, int w, int *rows, int *pitch, int *row0, int *wpp);
 int lic360_cconv4_ec_diag(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
                           const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
 int lic360_conv4_supported(const lic360_conv_plan *plan);
+/* packed4: nb * lic360_conv4_packed_floats(plan) floats = [nb nets, slot layout][nb nets, quad layout] -- the same weights twice: per (group, input
+ * group, lane class) slots for the v1 / v3 kernels, and with the registers of one double step adjacent per lane (one or two 16-byte loads per wave)
+ * for the v6 kernels (lic360_cconv4_dc_plane, lic360_cconv4_ec_diag).  Every lic360_cconv4_* call must be given the SAME nb the buffer was packed
+ * with: the second part starts nb * ngroup^2 * 512 floats into it. */
 long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);
 int lic360_cconv4_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
