@@ -47,6 +47,12 @@ struct ITerms {
         return s;
     }
     static constexpr int NQ = qbase(128);
+    // wave c of a workgroup owns lanes l = c + 8 a (a < 16) and runs their quads in (a, q) order: its "blocks" b = 0 .. nblocks(c) - 1
+    static constexpr int nblocks(int c) { int s = 0; for (int a = 0; a < 16; ++a) s += nquads(c + 8 * a); return s; }
+    static constexpr int blk_a(int c, int b) { int a = 0; while (b >= nquads(c + 8 * a)) { b -= nquads(c + 8 * a); ++a; } return a; }
+    static constexpr int blk_q(int c, int b) { int a = 0; while (b >= nquads(c + 8 * a)) { b -= nquads(c + 8 * a); ++a; } return b; }
+    static constexpr int ngroups() { int m = 0; for (int c = 0; c < 8; ++c) { const int g = (nblocks(c) + 3) / 4; m = g > m ? g : m; } return m; }
+    static constexpr int NG = ngroups();                     // groups of four blocks per wave (padded to the longest wave)
 };
 
 static inline bool conv144_ok(const lic360_conv_plan *p) {
@@ -57,17 +63,23 @@ template <int HIDDEN> static int i144_nq() { return ITerms<144, HIDDEN>::NQ; }
 static int conv144_nq(const lic360_conv_plan *p) { (void)p; return i144_nq<1>(); }
 static int conv144_otiles(const lic360_conv_plan *p) { return (p->nout + 15) / 16; }
 
-// packed144[otile][Q][lane 16 k + i] = w[16 otile + i][gid][tap] of the k-th term of quad Q (0 past a chain's end / past nout)
-__global__ void k_conv144_pack(const float *__restrict__ weight, const int *__restrict__ src, float *__restrict__ packed, int nout, int C, int NQ, long total) {
+// packed144[otile][wave c][group][lane 16 k + i][4]: word j of a lane's quad = w[16 otile + i][gid][tap] of the k-th term of the quad Q that wave c
+// runs as its block 4 group + j (0 past a chain's end / past nout / past the wave's last block).  A wave fetches the A operands of FOUR consecutive
+// MFMA blocks with one 16-byte load per lane (round 4: one global_load_dword per block kept the CU's address unit -- 9 cycles per wave instruction
+// of that width, 18 for a 16-byte one -- busy for more than half of the kernel; qmap: block -> Q per wave).
+__global__ void k_conv144_pack(const float *__restrict__ weight, const int *__restrict__ src, const int *__restrict__ qmap, float *__restrict__ packed,
+                               int nout, int C, int NG, long total) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int l = (int)(e & 63), i = l & 15, k = l >> 4;
-        const long t = e >> 6;
-        const int Q = (int)(t % NQ), ot = (int)(t / NQ), o = ot * 16 + i, s = src[Q * 4 + k];
+        const int jw = (int)(e & 3), l = (int)((e >> 2) & 63), i = l & 15, k = l >> 4;
+        const long t = e >> 8;
+        const int g = (int)(t % NG), c = (int)((t / NG) & 7), ot = (int)(t / (8 * NG)), o = ot * 16 + i;
+        const int Q = qmap[(c * NG + g) * 4 + jw];
+        const int s = Q >= 0 ? src[Q * 4 + k] : -1;
         packed[e] = (s >= 0 && o < nout) ? weight[(long)o * C * 25 + s] : 0.0f;         // s = gid * 25 + tap = the flat index itself
     }
 }
 template <int HIDDEN>
-static void i144_fill_src(int *src) {
+static void i144_fill_src(int *src, int *qmap) {
     using T = ITerms<144, HIDDEN>;
     int Q = 0;
     for (int l = 0; l < 128; ++l) {
@@ -75,21 +87,25 @@ static void i144_fill_src(int *src) {
         for (int q = 0; q < T::nquads(l); ++q, ++Q)
             for (int k = 0; k < 4; ++k) src[Q * 4 + k] = 4 * q + k < nt ? T::term(l, 4 * q + k) : -1;
     }
+    for (int c = 0; c < 8; ++c)
+        for (int b = 0; b < 4 * T::NG; ++b)
+            qmap[c * 4 * T::NG + b] = b < T::nblocks(c) ? T::qbase(c + 8 * T::blk_a(c, b)) + T::blk_q(c, b) : -1;
 }
 LIC360_API int lic360_conv144_supported(const lic360_conv_plan *p) { return p && conv144_ok(p) ? 1 : 0; }
 LIC360_API long lic360_conv144_packed_floats(const lic360_conv_plan *p) {
-    return p && conv144_ok(p) ? (long)conv144_otiles(p) * conv144_nq(p) * 64 : 0;
+    return p && conv144_ok(p) ? (long)conv144_otiles(p) * 8 * ITerms<144, 1>::NG * 256 : 0;
 }
 LIC360_API int lic360_conv144_pack(void *stream, const lic360_conv_plan *p, const float *weight, float *packed) {
     ARG_CHECK(p && conv144_ok(p) && weight && packed);
-    const int NQ = conv144_nq(p);
-    int *h = (int *)malloc(sizeof(int) * 4 * NQ), *d = nullptr;
-    i144_fill_src<1>(h);
-    hipError_t e = hipMalloc((void **)&d, sizeof(int) * 4 * NQ);
-    if (e == hipSuccess) e = hipMemcpyAsync(d, h, sizeof(int) * 4 * NQ, hipMemcpyHostToDevice, (hipStream_t)stream);
+    const int NQ = conv144_nq(p), NG = ITerms<144, 1>::NG, nint = 4 * NQ + 8 * 4 * NG;
+    int *h = (int *)malloc(sizeof(int) * nint), *d = nullptr;
+    i144_fill_src<1>(h, h + 4 * NQ);
+    hipError_t e = hipMalloc((void **)&d, sizeof(int) * nint);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, h, sizeof(int) * nint, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) {
         const long total = lic360_conv144_packed_floats(p);
-        hipLaunchKernelGGL(k_conv144_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, d, packed, p->nout, p->C, NQ, total);
+        hipLaunchKernelGGL(k_conv144_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, d, d + 4 * NQ, packed, p->nout, p->C, NG,
+                           total);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);          // h / d are released below
@@ -136,7 +152,7 @@ __device__ __forceinline__ unsigned i144_lds_addr(const float *p) {
 }
 __device__ __forceinline__ f32x4 i144_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-#define I144_PF 6                               // weight prefetch depth (blocks)
+#define I144_PFG 2                              // weight prefetch depth (groups of four blocks)
 
 template <int HIDDEN, bool DC, int NT, int WAVE>
 __device__ __forceinline__ void i144_body(const I144Args &a, float *xs, float *comb, const int tid, const int lane) {
@@ -184,25 +200,20 @@ __device__ __forceinline__ void i144_body(const I144Args &a, float *xs, float *c
         I144_WAIT0();
         __syncthreads();
         for (int ot = ot_lo; ot < ot_hi; ++ot) {
-            const float *wot = a.packed + (long)ot * T::NQ * 64 + lane;
+            const float *wot = a.packed + ((long)ot * 8 + WAVE) * (T::NG * 256) + lane * 4;
             f32x4 acc[NT][16];
-            // ---- the 16 chains of this wave, quad by quad; block index b runs over (a = lane slot, q) in order
-            float aring[I144_PF];
-            constexpr int NB = []() { int s = 0; for (int aa = 0; aa < 16; ++aa) s += T::nquads(WAVE + 8 * aa); return s; }();
-            // block b -> (lane slot aa, quad q) at compile time
-            auto blk_a = [](int b) constexpr { int aa = 0; while (b >= T::nquads(WAVE + 8 * aa)) { b -= T::nquads(WAVE + 8 * aa); ++aa; } return aa; };
-            auto blk_q = [](int b) constexpr { int aa = 0; while (b >= T::nquads(WAVE + 8 * aa)) { b -= T::nquads(WAVE + 8 * aa); ++aa; } return b; };
-            static_for<(I144_PF < NB ? I144_PF : NB)>([&](auto bb) {
-                constexpr int b = decltype(bb)::value, l = WAVE + 8 * blk_a(b), q = blk_q(b), woff = (T::qbase(l) + q) * 64;   // constexpr: folded, not looped at run time
-                aring[b % I144_PF] = wot[woff];
+            // ---- the 16 chains of this wave, quad by quad; block index b runs over (a = lane slot, q) in order; the A operands of blocks
+            // 4 g .. 4 g + 3 are one f32x4 per lane, fetched I144_PFG groups ahead
+            constexpr int NB = T::nblocks(WAVE), NGW = (NB + 3) / 4, RING = I144_PFG + 1;
+            f32x4 aring[RING];
+            static_for<(I144_PFG < NGW ? I144_PFG : NGW)>([&](auto gg) {
+                constexpr int g = decltype(gg)::value;
+                aring[g % RING] = *(const f32x4 *)(wot + g * 256);
             });
             static_for<NB>([&](auto bb) {
-                constexpr int b = decltype(bb)::value, aa = blk_a(b), q = blk_q(b), l = WAVE + 8 * aa;
-                const float av = aring[b % I144_PF];
-                if constexpr (b + I144_PF < NB) {
-                    constexpr int l2 = WAVE + 8 * blk_a(b + I144_PF), q2 = blk_q(b + I144_PF), woff2 = (T::qbase(l2) + q2) * 64;
-                    aring[b % I144_PF] = wot[woff2];
-                }
+                constexpr int b = decltype(bb)::value, aa = T::blk_a(WAVE, b), q = T::blk_q(WAVE, b), l = WAVE + 8 * aa;
+                if constexpr (b % 4 == 0 && b / 4 + I144_PFG < NGW) aring[(b / 4 + I144_PFG) % RING] = *(const f32x4 *)(wot + (b / 4 + I144_PFG) * 256);
+                const float av = aring[(b / 4) % RING][b % 4];
                 // B operand address: term k of the quad reads channel gid_k, tap_k (compile-time); past the chain's end any valid cell
                 constexpr int nt = T::nterms(l);
                 auto off_of = [](int k) constexpr {
