@@ -525,6 +525,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     float e_bias[2] = {0.f, 0.f}, e_act[2] = {0.f, 0.f}, e_res[2] = {0.f, 0.f};
     long e_oi[2] = {0, 0};
     bool e_ok = false;
+    int e_cq = -1;
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
     // FUSE: table build of a finished tile.  It runs at the top of the NEXT tile's first step -- where every accumulator is dead
     // (the first step starts all chains from C = 0), so its ~90 registers do not compete with them -- or after the loop.
@@ -564,11 +565,11 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                     const int rc = r < a.cout ? r : a.cout - 1;
                     const int o = gc * a.cout + rc, bid = (c_n / a.npb) * nout + o;
                     e_oi[rr] = ((long)c_n * nout + o) * PL + (long)((y < a.H ? y : a.H - 1) + 2) * a.wp + (x < a.W ? x : a.W - 1) + 2;
-                    e_bias[rr] = a.bias[bid];
-                    e_act[rr] = act_p[bid];
+                    if (e_cq != cq) { e_bias[rr] = a.bias[bid]; e_act[rr] = act_p[bid]; }   // once per task: the same for its four tiles (4 of a tile's 6 epilogue loads: -1 %)
                     e_res[rr] = res_p[a.residual ? e_oi[rr] : 0];
                 }
             }
+            e_cq = cq;
         }
         C16_T(0);
         if constexpr (CIN == 4) {
