@@ -333,7 +333,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     const int PS = PS_T >= 0 ? PS_T : ps_rt;
     static_assert(!FUSE || CIN == 4, "the fused table build belongs to the last (cin = 4) layer");
     constexpr int NSUB = FUSE ? 3 : 1;                                      // FUSE: the 3 stacked nets of an image, one after the other per tile
-    constexpr int GPB = FUSE ? C16_FGPB : 4, RPG = FUSE ? 3 : 4;            // groups per block, MFMA rows per group (row = RPG q + r)
+    constexpr int GPB = FUSE ? C16_FGPB : 4;                                // groups per block (MFMA row = 4 q + r, fused: 3 q + r)
     // tiles per task.  FUSE: the task's tiles are swept once per net (net 0 over all of them, then net 1, then net 2), so that the
     // workgroups of an XCD -- which start together and run equal task shapes -- stream ONE net's weights at a time (cycling the nets per
     // tile tripled the weight working set: 33 GB of fabric traffic per launch for 1.2 GB of algorithmic bytes); the nets' outputs wait
