@@ -1023,7 +1023,18 @@ def test_cconv16_dq_planes_bit_exact(lic, case):
     _cconv16_dc_planes(lic, case, "lic360_cconv16_dq_plane")
 
 
-def _cconv16_dc_planes(lic, case, entry):
+@pytest.mark.parametrize("case", [(12, 4, True, True, 2, 48, 40, 12), (12, 4, True, True, 1, 48, 64, 20), (6, 3, True, False, 3, 144, 18, 7),
+                                  (15, 4, False, True, 2, 32, 30, 30)],
+                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
+def test_cconv4_dc_planes_packed_bit_exact(lic, case):
+    """the production decode kernel (4x4x1 MFMAs, lic360_cconv4_dc_plane) plane by plane with its sample packing: THREE samples per task on the
+    corner diagonals that fit 14 rows (24 | samples per net: lanes 0..15 / 20..35 / 40..55, top and bottom windows), two per task where they
+    fit 26 rows (16 | samples per net), both in one launch (48 per net), neither (the middle diagonals); every case has more than 128 three-group
+    tasks per launch (fewer switch the kernel to its one-group-per-task latency mode, which does not pack)"""
+    _cconv16_dc_planes(lic, case, "lic360_cconv4_dc_plane", ("lic360_conv4_supported", "lic360_conv4_packed_floats", "lic360_conv4_pack"))
+
+
+def _cconv16_dc_planes(lic, case, entry, packfns=("lic360_conv16dc_supported", "lic360_conv16dc_packed_floats", "lic360_conv16dc_pack")):
     """lic360_cconv16_dc_plane (hidden / last layers of the latent nets in decode order: MFMA columns = input rows of one input
     anti-diagonal) on the lic360_dc4_layout: after every checked plane the persistent output equals the oracle's
     (extension/cconv_dc_cuda.cu:313-398) + residual; covers one sample per task on 64 rows, two samples per task on 32 rows
@@ -1057,15 +1068,17 @@ def _cconv16_dc_planes(lic, case, entry):
         return buf
     plan = C.c_void_p(0)
     assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
-    assert L.lic360_conv16dc_supported(plan) == 1
-    packed = torch.empty(nb * L.lic360_conv16dc_packed_floats(plan), dtype=torch.float32, device="cuda:0")
+    assert getattr(L, packfns[0])(plan) == 1
+    getattr(L, packfns[1]).restype = C.c_long
+    getattr(L, packfns[1]).argtypes = [C.c_void_p]
+    packed = torch.empty(nb * getattr(L, packfns[1])(plan), dtype=torch.float32, device="cuda:0")
     wd, bd = dev(w), dev(b)
     ad = dev(a) if act else None
     xd, rd = to_dev(skew(x)), to_dev(skew(res))
     out = to_dev(skew(np.zeros_like(res)))
     s = lic._stream(0)
     P = lic._p
-    assert L.lic360_conv16dc_pack(s, plan, P(wd), nb, P(packed)) == 0, L.lic360_last_error()
+    assert getattr(L, packfns[2])(s, plan, P(wd), nb, P(packed)) == 0, L.lic360_last_error()
     idx, pidx = orc.code_contex(H, W)
     ref = np.zeros((N, nout, H, W), np.float32)
     nplanes = H + W + G - 2
