@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16dc", "dc_hidden_16x16x4"), ("k_cconv16<4, false>", "ec_hidden"),
+CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16dc", "dc_hidden_16x16x4"), ("k_cconv16s", "ec_hidden"), ("k_cconv16<4, false>", "ec_hidden"),
            ("k_cconv16<4, true>", "ec_last"), ("k_cconv16<1, false>", "ec_first")]
 out_json, images = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
