@@ -135,22 +135,9 @@ LIC360_API int lic360_ec16_layout(int h, int w, int *hp, int *wp) {
 #define C16_WAIT_PREV() asm volatile("s_waitcnt vmcnt(" C16_STR(C16_NDMA) ")" ::: "memory")   // all but the youngest step's DMAs
 #define C16_NDMA4 10                       // cin = 4: the four waves of set 0 issue the whole step image, 10 windows each
 #define C16_WAIT_PREV4() asm volatile("s_waitcnt vmcnt(" C16_STR(C16_NDMA4) ")" ::: "memory")
-// KIND: 0 = a window of x halo tiles, 1 = a window of packed weights (timing ablations C16_EXP_NOXDMA / NOWDMA / DMAADDR only)
+// KIND: 0 = a window of x halo tiles, 1 = a window of packed weights
 template <int KIND = 1>
 __device__ __forceinline__ void c16_dma_x4(const float *src, unsigned lds_byte_addr) {
-#ifdef C16_EXP_NODMA
-    return;
-#endif
-#ifdef C16_EXP_NOXDMA
-    if (KIND == 0) return;
-#endif
-#ifdef C16_EXP_NOWDMA
-    if (KIND == 1) return;
-#endif
-#ifdef C16_EXP_DMAADDR                                                        // the address arithmetic without the instruction
-    asm volatile("" ::"v"(src), "s"(lds_byte_addr) : "memory");
-    return;
-#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 // the form the kernels use: 64-bit UNIFORM base (SGPR pair) + 32-bit per-lane byte offset.  The per-lane offsets are loop-invariant registers and a
@@ -159,19 +146,6 @@ __device__ __forceinline__ void c16_dma_x4(const float *src, unsigned lds_byte_a
 // address arithmetic kept ran as slowly as the full kernel (tools/ec_stamp.sh -DC16_EXP_DMAADDR).
 template <int KIND = 1>
 __device__ __forceinline__ void c16_dma_s(unsigned voff, const float *sbase, unsigned lds_byte_addr) {
-#ifdef C16_EXP_NODMA
-    return;
-#endif
-#ifdef C16_EXP_NOXDMA
-    if (KIND == 0) return;
-#endif
-#ifdef C16_EXP_NOWDMA
-    if (KIND == 1) return;
-#endif
-#ifdef C16_EXP_DMAADDR
-    asm volatile("" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-    return;
-#endif
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ const float *c16_uniform(const float *p) {     // the value IS wave-uniform; this tells the compiler
@@ -226,12 +200,6 @@ struct C16Ops { float a, b[C16_NT]; };
 template <int CLS, int TAP>
 __device__ __forceinline__ void c16_load4(C16Ops &o, const float *xs, const float *ws) {
     constexpr int kh = TAP / 5, kw = TAP % 5, gid = (CLS - TAP) & 3;
-#ifdef C16_EXP_NOLDS
-    o.a = __builtin_bit_cast(float, TAP + 0x3f800000);
-    for (int t = 0; t < C16_NT; ++t) o.b[t] = __builtin_bit_cast(float, t + kh + 0x3f000000);
-    asm volatile("" : "+v"(o.a), "+v"(o.b[0]), "+v"(o.b[1]));
-    return;
-#endif
     o.a = ws[TAP * 64];
 #pragma unroll
     for (int t = 0; t < C16_NT; ++t) o.b[t] = xs[gid * C16_PLANE + (kh + t) * C16_HC + kw];
@@ -309,11 +277,7 @@ __device__ __attribute__((noinline)) void c16_tables_phase(c16_lds_f *comb, int 
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[net * 3 + c] = comb[C16_COMB + (((tt * 3 + net) * GPB + q) * 3 + c) * 64 + pos];
         int Tb[9];
-#ifdef C16_EXP_NOTAB                                                          // ablation (timing only): what the CDF arithmetic of the table phase costs
-        for (int e = 0; e < 9; ++e) Tb[e] = (int)v[e];
-#else
         gmm_cdf9(v, v + 3, v + 6, Tb);                                      // softmax, sigma floor, erf CDF, fix-up: entropy_gmm_table_cuda.cu:29-107,138-159
-#endif
         int sym = (int)code[(((long)tb_n * G + g) * H + th) * W + tw];
         sym = sym < 0 ? 0 : (sym > 7 ? 7 : sym);
         rec[record_at(g, th, tw)] = make_uint2((unsigned)Tb[sym], (unsigned)Tb[sym + 1]);
@@ -594,13 +558,6 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 c16_range4<CLS, 1, true>(acc, xs, ws, ops, true, nohook);
                 c16_range4<CLS, 2, true>(acc, xs, ws, ops, false, nohook);
             } else {
-#ifdef C16_EXP_REPEAT
-                for (int rep = 0; rep < C16_EXP_REPEAT - 1; ++rep) {
-                    c16_range4<CLS, 0, false>(acc, xs, ws, ops, true, nohook);
-                    c16_range4<CLS, 1, false>(acc, xs, ws, ops, true, nohook);
-                    c16_range4<CLS, 2, false>(acc, xs, ws, ops, true, nohook);
-                }
-#endif
                 c16_range4<CLS, 0, false>(acc, xs, ws, ops, dl > 4, dmahook);
                 if constexpr (!DMA0) issue_advance();
                 if (dl > 4) c16_range4<CLS, 1, false>(acc, xs, ws, ops, dl > 6, nohook);
@@ -628,11 +585,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
             });
         }
         C16_T(1);
-#ifdef C16_EXP_NOEPI
-        if (last && c_n < 0) {
-#else
         if (last) {
-#endif
 #pragma unroll
             for (int t = 0; t < C16_NT; ++t) {
                 const f32x4 part = tree4_eval<CIN, CLS>(acc[t]);
@@ -656,9 +609,6 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
             }
         } else C16_WAIT_PREV();                                             // own DMAs of the NEXT step (issued a step ago) have landed
         C16_T(3);
-#ifdef C16_EXP_NOBAR
-        if (last)
-#endif
         __syncthreads();
         C16_T(4);
 #ifdef C16_STAMP
@@ -667,9 +617,6 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         if (last) {
             // wave w finishes tile row w >> 1, output channels 2 (w & 1), 2 (w & 1) + 1 of the four groups: (F0 + F2) + (F1 + F3)
             const int trow = WAVE >> 1;
-#ifdef C16_EXP_NOEPI
-            if (c_n < 0)
-#endif
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int rbase = 2 * (WAVE & 1);
@@ -727,9 +674,6 @@ __global__ __launch_bounds__(C16_THREADS, 2) void k_cconv16(C16Args a) {
     __shared__ int tq[8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef C16_PRIO
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);                           // (experiment) static priority for the younger wave of every SIMD
-#endif
     const int ps = wave >> 2;
     if constexpr (!FUSE) {
         switch (wave) {
@@ -1099,7 +1043,7 @@ static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w, in
     a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
     a.n_chunks = (a.ntiles + tpt - 1) / tpt;
     a.NS = conv16_nsteps_max(p);
-    { static const int k = getenv("LIC360_C16_K") ? atoi(getenv("LIC360_C16_K")) : 16; a.gbk = k > 0 ? k : 1; }
+    a.gbk = 16;                                                             // task-order block size (blocks of 4 .. all measured: DESIGN 4.1 a)
     a.code = a.mask = nullptr; a.pidx = a.plane_start = nullptr; a.rec = nullptr;
     return 0;
 }
@@ -1114,10 +1058,9 @@ LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const 
     if (c16_fill_args(a, p, h, w)) return 2;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));
-    // cin = 4: the skewed form (k_cconv16s) when every tile has at least two steps; LIC360_EC_SKEW=0 keeps the lockstep kernel
-    static const bool skew = !(getenv("LIC360_EC_SKEW") && atoi(getenv("LIC360_EC_SKEW")) == 0);
+    // cin = 4: the skewed form (k_cconv16s) when every tile has at least two steps; nets of fewer than five groups keep the lockstep kernel
     const int l0 = 3 + 4 + a.hidden, l0c = l0 < p->ngroup ? l0 : p->ngroup;     // chain length of the first group block
-    if (p->cin == 4 && skew && l0c > 4) hipLaunchKernelGGL(k_cconv16s, dim3(256), dim3(C16_THREADS), 0, s, a);
+    if (p->cin == 4 && l0c > 4) hipLaunchKernelGGL(k_cconv16s, dim3(256), dim3(C16_THREADS), 0, s, a);
     else if (p->cin == 4) hipLaunchKernelGGL((k_cconv16<4, false>), dim3(256), dim3(C16_THREADS), 0, s, a);
     else hipLaunchKernelGGL((k_cconv16<1, false>), dim3(256), dim3(C16_THREADS), 0, s, a);
     LAUNCH_CHECK();

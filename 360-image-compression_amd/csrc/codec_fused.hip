@@ -33,16 +33,13 @@ struct lic360_codec {
     int G, H, W, maxB, S, P, HW;
     int sk_rows, sk_pitch, sk_row0, sk_col0;
     int e_hp, e_wp, e_off;                     // encode activation planes: [e_hp][e_wp], cell (r, c) at [(r+e_off)*e_wp + c+e_off]
-    int e_wpp = 0;                             // > 0: wrapped diagonal-major planes instead (lic360_ec6_layout): [e_hp rows][e_wp = h+4]   // diagonal-major decode layout: cell (s, th) at [(s + row0) * pitch + th + col0]
     lic360_conv_plan *plan[3];                 // first, hidden, last
     float *packed[12], *bias[12], *act[12];
     float *packed4[12];                        // leaf-resident (4x4x1 MFMA) weight layout, when the shape allows it
     float *packed16[12];                       // 16x16x4 MFMA weight layout of the encode-order kernel (csrc/cconv16_kernels.hip)
-    float *packed16dc[12];                     // weight layout of the decode-order 16x16x4 kernel (csrc/cconv16dc_kernels.hip), layers 1..11
-    bool use16dc = false;                      // LIC360_DC=16 / q: hidden + last decode layers on the 16x16x4 kernel (opt-in; the default is the 4x4x1 kernel)
-    bool use16dq = false;                      // LIC360_DC=q: its class-sequential 4-wave form where the batch qualifies
-    bool use4, use16, fuse_tables = true;      // fuse_tables: LIC360_EC_FUSE=0 keeps the separate table kernel (A/B runs)
-    int dc_mode = 0;                           // A/B switches of the decode kernel, read from the environment once, at create
+    bool use4;                                 // the nets' shapes fit the specialised kernels (4x4x1 decode order, 16x16x4 encode order with the last layer
+                                               // fused with the CDF tables); otherwise -- or under LIC360_FUSED_CONV=16 -- the generic kernels of cconv_kernels.hip
+    int dc_mode = 0;                           // schedule switches of the decode kernel (LIC360_NOPACK, LIC360_DC_GSTEP), read from the environment once, at create
     int *e_ctr = nullptr;                      // 8 task counters of the encode kernel
     std::vector<int> h_idx, h_pidx, h_plane_start;
     int *d_idx, *d_pidx, *d_plane_start;
@@ -79,26 +76,15 @@ static int plan_of(int layer) { return layer == 0 ? 0 : (layer == 11 ? 2 : 1); }
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // ------------------------------------------------------------------------------------------------ encode
-// offset of cell (r, c) inside one encode activation plane; wpp > 0 selects the wrapped diagonal-major layout, whose
-// first / last diagonals are stored twice (*dup = offset of the second copy, or -1)
-__device__ __forceinline__ long e_cell(int r, int c, int hp, int wp, int off, int wpp, long *dup) {
-    *dup = -1;
-    if (wpp == 0) return (long)(r + off) * wp + c + off;
-    const int sg = (r + c + 2) % wpp, r0 = off;                             // off carries the row of diagonal 0
-    if (sg < hp - wpp - r0) *dup = (long)(sg + r0 + wpp) * wp + r + 2;
-    else if (sg >= wpp - r0) *dup = (long)(sg + r0 - wpp) * wp + r + 2;
-    return (long)(sg + r0) * wp + r + 2;
-}
+// offset of cell (r, c) inside one encode activation plane (zero-haloed NCHW, or plain NCHW with off = 0 for the generic kernels)
+__device__ __forceinline__ long e_cell(int r, int c, int wp, int off) { return (long)(r + off) * wp + c + off; }
 
 __global__ void k_enc_prep(const float *__restrict__ code, const float *__restrict__ mask, float *__restrict__ x0, long total,
-                           int H, int W, int hp, int wp, int off, int wpp) {
+                           int H, int W, int hp, int wp, int off) {
     GRID_STRIDE(i, total) {
         int c = (int)(i % W), r = (int)((i / W) % H);
-        long pl = i / ((long)H * W), dup;
-        const long o = e_cell(r, c, hp, wp, off, wpp, &dup);
-        const float v = (code[i] - 3.5f) * mask[i];                                  // lic360_demo.py:130
-        x0[pl * hp * wp + o] = v;
-        if (dup >= 0) x0[pl * hp * wp + dup] = v;
+        long pl = i / ((long)H * W);
+        x0[pl * hp * wp + e_cell(r, c, wp, off)] = (code[i] - 3.5f) * mask[i];       // lic360_demo.py:130
     }
 }
 
@@ -107,7 +93,7 @@ __global__ void k_enc_prep(const float *__restrict__ code, const float *__restri
 // plane, rows ascending inside a diagonal (extension/code_contex_cuda.cu:19-31, tile_extract_cuda.cu:36-41).
 __global__ void k_enc_tables(const float *__restrict__ y, const float *__restrict__ code, const float *__restrict__ mask,
                              const int *__restrict__ pidx, const int *__restrict__ plane_start, uint2 *__restrict__ rec,
-                             int B, int G, int H, int W, int hp, int wp, int off, int wpp) {
+                             int B, int G, int H, int W, int hp, int wp, int off) {
     const long HW = (long)H * W, per = (long)G * HW, total = per * B;
     GRID_STRIDE(i, total) {
         int tw = (int)(i % W), th = (int)((i / W) % H), g = (int)((i / HW) % G), b = (int)(i / per);
@@ -117,8 +103,7 @@ __global__ void k_enc_tables(const float *__restrict__ y, const float *__restric
         uint2 r = make_uint2(0u, 0u);
         if (!(mask[i] < 0.5f)) {                                     // coder.cpp:79
             float v[9];
-            long dup;
-            const long cell = e_cell(th, tw, hp, wp, off, wpp, &dup);
+            const long cell = e_cell(th, tw, wp, off);
 #pragma unroll
             for (int net = 0; net < 3; ++net)
 #pragma unroll
@@ -603,14 +588,15 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     lic360_codec *c = new lic360_codec();
     memset(c->layer_set, 0, sizeof(c->layer_set));
     c->G = ngroup; c->H = h; c->W = w; c->maxB = max_batch; c->S = h + w - 1; c->P = h + w + ngroup - 2; c->HW = h * w;
-    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = c->packed16[i] = c->packed16dc[i] = nullptr;
+    for (int i = 0; i < 12; ++i) c->packed[i] = c->bias[i] = c->act[i] = c->packed4[i] = c->packed16[i] = nullptr;
     int rc = 0;
     rc |= lic360_conv_plan_create(ngroup * 1, ngroup, ngroup * 4, 5, 5, &c->plan[0]);
     rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 4, 5, 6, &c->plan[1]);
     rc |= lic360_conv_plan_create(ngroup * 4, ngroup, ngroup * 3, 5, 6, &c->plan[2]);
     if (rc) return 1;
-    const char *force = getenv("LIC360_FUSED_CONV");                  // "16" forces the 16x16x4 kernels (A/B comparisons)
+    const char *force = getenv("LIC360_FUSED_CONV");                  // "16" forces the generic 16x16x4 kernels (the fall-back path, kept tested)
     c->use4 = lic360_conv4_supported(c->plan[0]) && lic360_conv4_supported(c->plan[1]) && lic360_conv4_supported(c->plan[2]) &&
+              lic360_conv16_supported(c->plan[0]) && lic360_conv16_supported(c->plan[1]) && lic360_conv16_supported(c->plan[2]) &&
               !(force && force[0] == '1' && force[1] == '6');
     c->h_idx.resize(2 * (size_t)c->HW);
     c->h_pidx.resize(h + w);
@@ -635,22 +621,11 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     if (c->use4) { if (lic360_dc4_layout(h, w, &c->sk_rows, &c->sk_pitch, &c->sk_row0, &c->sk_col0)) return 1; }
     else { c->sk_rows = c->S; c->sk_pitch = h; c->sk_row0 = 0; c->sk_col0 = 0; }
     const size_t B = max_batch, G = ngroup, HW = c->HW, SK = (size_t)c->sk_rows * c->sk_pitch, TAIL = (size_t)lic360_conv4_buffer_floats(0, 1, h, w) - (size_t)c->sk_rows * c->sk_pitch;   // slack for the band fetches of the last plane
-    // encode-order kernel (environment read once, here): default = 16x16x4 MFMA on zero-haloed NCHW planes; LIC360_EC=6 the
-    // 4x4x1 kernel on wrapped diagonal-major planes, LIC360_EC4=3 (or LIC360_EC=3) the row-major LDS-DMA kernel (A/B runs)
-    const char *force_ec4 = getenv("LIC360_EC4"), *force_ec = getenv("LIC360_EC");
-    const int ec_mode = (force_ec4 && force_ec4[0] == '3') || (force_ec && force_ec[0] == '3') ? 3 : ((force_ec && force_ec[0] == '6') ? 6 : 16);
     c->dc_mode = lic360_dc4_env_mode();
-    c->use16 = c->use4 && ec_mode == 16 && lic360_conv16_supported(c->plan[0]) && lic360_conv16_supported(c->plan[1]) && lic360_conv16_supported(c->plan[2]);
-    { const char *fd = getenv("LIC360_DC");                           // decode order, hidden + last layers: "16" = the 16x16x4 MFMA kernel
-      c->use16dq = fd && fd[0] == 'q';
-      c->use16dc = c->use4 && h <= 64 && (fd && ((fd[0] == '1' && fd[1] == '6') || fd[0] == 'q')) && lic360_conv16dc_supported(c->plan[1]) && lic360_conv16dc_supported(c->plan[2]); }
-    if (c->use16) { if (lic360_ec16_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
-    else if (c->use4 && w >= 7 && ec_mode != 3) {
-        if (lic360_ec6_layout(h, w, &c->e_hp, &c->e_wp, &c->e_off, &c->e_wpp)) return 1;
-    } else if (c->use4) { if (lic360_ec4_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
+    // encode order: 16x16x4 MFMA kernels on zero-haloed NCHW planes, or plain NCHW for the generic kernels
+    if (c->use4) { if (lic360_ec16_layout(h, w, &c->e_hp, &c->e_wp)) return 1; c->e_off = 2; }
     else { c->e_hp = h; c->e_wp = w; c->e_off = 0; }
     rc |= dmalloc(&c->e_ctr, 8);
-    { const char *f = getenv("LIC360_EC_FUSE"); c->fuse_tables = !(f && f[0] == '0'); }
     const size_t EPL = (size_t)c->e_hp * c->e_wp;
     rc |= dmalloc(&c->e_x0, B * G * EPL + TAIL);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], 3 * B * 4 * G * EPL + TAIL);
@@ -681,7 +656,7 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
     (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab); (void)hipFree(c->e_ctr);
-    for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed16[i]); (void)hipFree(c->packed16dc[i]); }
+    for (int i = 0; i < 12; ++i) (void)hipFree(c->packed16[i]);
     for (int k = 0; k < PROF_NCLS; ++k)
         for (hipEvent_t e : c->ev[k]) (void)hipEventDestroy(e);
     delete c;
@@ -697,15 +672,13 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
         if (dmalloc(&c->bias[layer], 3 * (size_t)p->nout)) return 1;
         if (act && dmalloc(&c->act[layer], 3 * (size_t)p->nout)) return 1;
         if (c->use4 && dmalloc(&c->packed4[layer], 3 * (size_t)lic360_conv4_packed_floats(p))) return 1;
-        if (c->use16 && dmalloc(&c->packed16[layer], 3 * (size_t)lic360_conv16_packed_floats(p))) return 1;
-        if (c->use16dc && layer >= 1 && dmalloc(&c->packed16dc[layer], 3 * (size_t)lic360_conv16dc_packed_floats(p))) return 1;
+        if (c->use4 && dmalloc(&c->packed16[layer], 3 * (size_t)lic360_conv16_packed_floats(p))) return 1;
     }
     if (lic360_conv_pack(stream, p, weight, 3, c->packed[layer])) return 1;
     if (c->use4 && lic360_conv4_pack(stream, p, weight, 3, c->packed4[layer])) return 1;
     // (the fused last layer + CDF tables reads a packing of its own: five groups per block)
-    if (c->use16 && ((layer == 11 && c->fuse_tables) ? lic360_conv16_pack_tables(stream, p, weight, 3, c->packed16[layer])
-                                                      : lic360_conv16_pack(stream, p, weight, 3, c->packed16[layer]))) return 1;
-    if (c->use16dc && layer >= 1 && lic360_conv16dc_pack(stream, p, weight, 3, c->packed16dc[layer])) return 1;
+    if (c->use4 && (layer == 11 ? lic360_conv16_pack_tables(stream, p, weight, 3, c->packed16[layer])
+                                : lic360_conv16_pack(stream, p, weight, 3, c->packed16[layer]))) return 1;
     HIP_TRY(hipMemcpyAsync(c->bias[layer], bias, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (act) HIP_TRY(hipMemcpyAsync(c->act[layer], act, 3 * (size_t)p->nout * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->layer_set[layer] = true;
@@ -726,14 +699,12 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     hipStream_t s = (hipStream_t)stream;
     const int G = c->G, H = c->H, W = c->W;
     const long total = (long)B * G * c->HW;
-    hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp);
+    hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total, H, W, c->e_hp, c->e_wp, c->e_off);
     LAUNCH_CHECK();
     float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
     auto ec = [&](int layer, const float *xin, const float *res, float *dst, int x_mod) -> int {
         lic360_conv_plan *p = c->plan[plan_of(layer)];
-        if (c->use16) return lic360_cconv16_ec(stream, p, xin, c->packed16[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod, c->e_ctr);
-        if (c->e_wpp) return lic360_cconv4_ec_diag(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
-        if (c->use4) return lic360_cconv4_ec_padded(stream, p, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
+        if (c->use4) return lic360_cconv16_ec(stream, p, xin, c->packed16[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod, c->e_ctr);
         return lic360_cconv_ec_ex(stream, p, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
     };
     int rc = 0;
@@ -745,7 +716,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
         float *tmp = cur; cur = nxt; nxt = tmp;
     }
     if (rc) return 1;
-    if (c->use16 && c->fuse_tables) {
+    if (c->use4) {
         // last layer + CDF tables in one kernel: the nets' outputs never reach HBM (no y buffer, no k_enc_tables)
         PROF(c, PROF_EC_LAST, s, rc |= lic360_cconv16_ec_tables(stream, c->plan[2], cur, c->packed16[11], c->bias[11], code, mask, c->d_pidx,
                                                                 c->d_plane_start, c->e_rec, B, H, W, c->e_ctr));
@@ -757,7 +728,7 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     PROF(c, PROF_EC_LAST, s, rc |= ec(11, cur, nullptr, t1, 3 * B));
     if (rc) return 1;
     PROF(c, PROF_ENC_TABLES, s, hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx,
-                                                   c->d_plane_start, c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off, c->e_wpp));
+                                                   c->d_plane_start, c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off));
     LAUNCH_CHECK();
     PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
     LAUNCH_CHECK();
@@ -775,15 +746,6 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
     const int *pih = c->h_pidx.data();
     auto dc = [&](int layer, const float *xin, const float *res, float *dst, int x_mod, int p) -> int {
         lic360_conv_plan *pl = c->plan[plan_of(layer)];
-        // hidden / last layers: the input-stationary 16x16x4 kernel, except in latency mode (few samples: the 4x4x1 kernel's
-        // one-group tasks spread a plane over more workgroups)
-        if (c->use16dc && layer >= 1 && (long)3 * B * ((G + 2) / 3) > 128) {
-            if (c->use16dq) {
-                const int rc = lic360_cconv16_dq_plane(stream, pl, xin, c->packed16dc[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
-                if (rc != 3) return rc;
-            }
-            return lic360_cconv16_dc_plane(stream, pl, xin, c->packed16dc[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod);
-        }
         if (c->use4) return lic360_cconv4_dc_plane_mode(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod, c->dc_mode);
         return lic360_cconv_dc_plane_ex(stream, pl, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3,
                                         c->d_idx, c->d_pidx, pih, p, x_mod, 1);
@@ -857,7 +819,7 @@ struct lic360_impcodec {
     std::vector<hipEvent_t> plane_ev;
     long gate_gen = 0;
     bool gate_armed = false;
-    int gate_stride = 0;
+    int gate_stride = 0, gate_B = 0;           // gate_B: the batch whose mask rows the armed masked decode fills
     const float *gate_mask = nullptr;
 };
 #define IMP_TW 64                              // ints per table row (nsym + 1 <= 64), one per lane
@@ -996,7 +958,7 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], B * CE * HW);
     rc |= dmalloc(&c->e_rec, B * HW);
     // 144-channel layers on the leaf-resident 16x16x4 kernels (LIC360_IMP144=0 keeps the generic kernels: A/B runs)
-    { const char *f = getenv("LIC360_IMP144"); c->use144 = lic360_conv144_supported(c->plan[1]) && lic360_conv144_supported(c->plan[2]) && !(f && f[0] == '0'); }
+    c->use144 = lic360_conv144_supported(c->plan[1]) && lic360_conv144_supported(c->plan[2]);
     if (c->use144) {
         if (lic360_ec144_layout(h, w, &c->e_hp, &c->e_wp) || lic360_dc144_layout(h, w, &c->sk_rows, &c->sk_pitch)) return 1;
         c->sk_row0 = 4; c->sk_col0 = 2;
@@ -1200,6 +1162,7 @@ LIC360_API int lic360_impcodec_decode_masked(void *stream, lic360_impcodec *c, c
     c->gate_armed = rc == 0;                                            // (a failed enqueue arms nothing)
     if (rc) return rc;
     c->gate_stride = stride;
+    c->gate_B = B;
     c->gate_mask = mask_out;
     *generation_out = ++c->gate_gen;
     return 0;
@@ -1222,6 +1185,13 @@ LIC360_API int lic360_codec_decode_gated(void *stream, lic360_codec *c, const ui
         lic360_set_error("lic360_codec_decode_gated: `mask` is not the buffer the masked decode of generation %ld fills", generation);
         return 2;
     }
+    if (B > map_codec->gate_B) {
+        lic360_set_error("lic360_codec_decode_gated: batch %d, but the masked decode of generation %ld fills the mask of %d images", B, generation, map_codec->gate_B);
+        return 2;
+    }
+    // a call that is rejected for its own arguments must not burn the ticket: the checks codec_decode_impl starts with, first
+    if (check_ready(c, B)) return 2;
+    ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     map_codec->gate_armed = false;
     return codec_decode_impl(stream, c, bytes, cap, nbytes, mask, B, code_out, err, (void *const *)map_codec->plane_ev.data(), map_codec->P,
                              map_codec->gate_stride);

@@ -159,37 +159,19 @@ int lic360_cconv_dc_plane_ex(void *stream, const lic360_conv_plan *plan, const f
                              const float *act, const float *residual, float *out, int n, int h, int w, int nb,
                              const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod, int skewed);
 
-/* Leaf-resident variant (v_mfma_f32_4x4x1, csrc/cconv4_kernels.hip) for the latent-net shapes cin in {1,4},
- * cout <= 4, ngroup <= 64: same results bit for bit, own weight layout.  EC: NCHW.  DC: zero-padded diagonal-major
- * activations [n][c][rows][pitch] with cell (s = th+tw, th) at [(s + row0) * pitch + th + col0] (lic360_dc4_layout; the
- * padding must be zero), min(h,w) <= 64.
- * Buffers of the three lic360_conv4 layouts are sized with lic360_conv4_buffer_floats(layout, planes, h, w) -- layout 0 = dc4,
- * 1 = ec4, 2 = ec6; planes = samples x channels -- which includes the slack the 16-byte band fetches of the last plane may touch
- * (whole quads of 11-row bands, not clamped at the end of the tensor); the whole buffer starts zeroed. */
+/* Decode order, leaf-resident variant (v_mfma_f32_4x4x1, csrc/cconv4_kernels.hip + cconv4v6_dc.inc) for the latent-net shapes cin in {1,4},
+ * cout <= 4, ngroup <= 64: replaces CconvDcOp.forward_act_batch / forward_batch of one plane (extension/cconv_dc_cuda.cu:313-398), same
+ * results bit for bit as lic360_cconv_dc_plane, own weight layout.  Activations: zero-padded diagonal-major [n][c][rows][pitch] with cell
+ * (s = th+tw, th) at [(s + row0) * pitch + th + col0] (lic360_dc4_layout; the padding must be zero).  Buffers are sized with
+ * lic360_conv4_buffer_floats(0, planes, h, w) -- planes = samples x channels -- which includes the slack the 16-byte band fetches of the
+ * last plane may touch (whole quads of 11-row bands, not clamped at the end of the tensor); the whole buffer starts zeroed. */
 long lic360_conv4_buffer_floats(int layout, long planes, int h, int w);
 int lic360_dc4_layout(int h, int w, int *rows, int *pitch, int *row0, int *col0);
-/* encode order on zero-padded NCHW planes [hp][wp] with cell (r, c) at [(r+2)*wp + c+2] (lic360_ec4_layout): unconditional
- * 16-byte LDS-DMA tile fetches, persistent workgroups; the padding must be zero, buffers sized by lic360_conv4_buffer_floats(1, ...) */
-int lic360_ec4_layout(int h, int w, int *hp, int *wp);
-int lic360_cconv4_ec_padded(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
-                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
-/* encode order on wrapped diagonal-major planes (h <= 64): `rows` x `pitch` floats per channel, cell (th, tw) on wrapped
- * diagonal sg = (th + tw + 2) % wpp at [(sg + row0) * pitch + th + 2]; diagonals sg < rows - wpp - row0 are stored a second
- * time at row sg + row0 + wpp, diagonals sg >= wpp - row0 a second time at row sg + row0 - wpp (so that the 11-row halo band
- * of any position set is contiguous); everything else stays zero.  Same arithmetic as lic360_cconv_ec
- * (extension/cconv_ec_cuda.cu:271-331), one LDS read per tap diagonal. */
-int lic360_ec6_layout(int h, int w, int *rows, int *pitch, int *row0, int *wpp);
-int lic360_cconv4_ec_diag(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
-                          const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
 int lic360_conv4_supported(const lic360_conv_plan *plan);
-/* packed4: nb * lic360_conv4_packed_floats(plan) floats = [nb nets, slot layout][nb nets, quad layout] -- the same weights twice: per (group, input
- * group, lane class) slots for the v1 / v3 kernels, and with the registers of one double step adjacent per lane (one or two 16-byte loads per wave)
- * for the v6 kernels (lic360_cconv4_dc_plane, lic360_cconv4_ec_diag).  Every lic360_cconv4_* call must be given the SAME nb the buffer was packed
- * with: the second part starts nb * ngroup^2 * 512 floats into it. */
+/* packed4: nb * lic360_conv4_packed_floats(plan) floats: per (net, output group) blocks of 4 KB in which the registers a wave needs for one
+ * double step are adjacent per lane (one or two 16-byte loads per wave and double step) */
 long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);
-int lic360_cconv4_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
-                     const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod);
 int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
 
@@ -207,23 +189,6 @@ int lic360_conv16_pack(void *stream, const lic360_conv_plan *plan, const float *
 int lic360_conv16_pack_tables(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16);
 int lic360_cconv16_ec(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16, const float *bias,
                       const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr);
-
-/* Decode-order variant on v_mfma_f32_16x16x4_f32 (csrc/cconv16dc_kernels.hip) for the hidden / last layers of the latent nets
- * (cin = 4, cout <= 4, h <= 64): replaces CconvDcOp.forward_act_batch / forward_batch of one plane
- * (extension/cconv_dc_cuda.cu:313-398) on the lic360_dc4_layout activations, same results bit for bit as lic360_cconv4_dc_plane.
- * MFMA columns = input rows of one input anti-diagonal, MFMA rows = every chain (group, channel, tap) that reads that diagonal
- * (they all have the same length); own weight layout (lic360_conv16dc_pack). */
-int lic360_conv16dc_supported(const lic360_conv_plan *plan);
-long lic360_conv16dc_packed_floats(const lic360_conv_plan *plan);
-int lic360_conv16dc_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed16dc);
-int lic360_cconv16_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
-                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
-/* The same plane, same arithmetic and same packed weights on 4-wave workgroups that walk the four lane classes of a task one after the
- * other (two independent workgroups per CU, no class combine through LDS).  Needs 8 | n, 16 | n / nb and x_mod == n (the two / four
- * samples of a task share a net and lie 8 apart in n); returns 3 -- nothing launched -- for other batches: call
- * lic360_cconv16_dc_plane then.  Replaces the same reference call (extension/cconv_dc_cuda.cu:313-398). */
-int lic360_cconv16_dq_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed16dc, const float *bias,
-                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
 
 /* Last layer of the latent entropy model with the CDF-table build fused into its epilogue (SURVEY.md §7 k_cconv_ec_last_gmm;
  * replaces the last CconvEcBatch.forward + TileExtractBatch + EntropyBatchGmmTable.forward_batch of

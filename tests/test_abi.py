@@ -46,9 +46,7 @@ def test_layout_queries_and_buffer_sizes_run_without_a_gpu():
     need = L.lic360_conv4_buffer_floats(0, planes, 64, 128)
     assert need > planes * rows.value * pitch.value and need - planes * rows.value * pitch.value <= 1 << 14
     hp, wp = ctypes.c_int(), ctypes.c_int()
-    assert L.lic360_ec4_layout(64, 128, ctypes.byref(hp), ctypes.byref(wp)) == 0
-    assert L.lic360_conv4_buffer_floats(1, planes, 64, 128) > planes * hp.value * wp.value
-    assert L.lic360_conv4_buffer_floats(2, planes, 64, 5) == 0          # the wrapped-diagonal layout needs w >= 7
+    assert L.lic360_ec16_layout(64, 128, ctypes.byref(hp), ctypes.byref(wp)) == 0 and (hp.value, wp.value) == (68, 132)
     assert L.lic360_conv4_buffer_floats(7, planes, 64, 128) == 0 and L.lic360_conv4_buffer_floats(0, 0, 64, 128) == 0
     # importance-net decode layout: any map height (maps taller than a task window are cut into diagonal segments)
     for h, w in ((32, 64), (64, 128), (5, 3)):

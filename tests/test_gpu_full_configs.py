@@ -83,22 +83,3 @@ def test_batch_of_cfg3_images():
     streams = fc.encode(dev(code8), dev(mask8))
     assert streams[0] == g["bytes"].tobytes() and streams[1] == gb["bytes"].tobytes()
     assert np.array_equal(fc.decode(streams, dev(mask8)).cpu().numpy(), code8 * mask8)
-
-
-def test_batch_of_cfg3_images_on_the_16x16x4_decode_kernel(monkeypatch):
-    """the same 8-image batch decoded with LIC360_DC=16 (hidden / last layers on csrc/cconv16dc_kernels.hip, full 48x64x128 size: one
-    sample per task on 64 rows, two per task on the corner planes): image 0's stream is the ORACLE's bytes"""
-    g, shape, code, mask, levels, layers, imp_layers = load("cfg3")
-    G, H, W = shape
-    codes, masks = [code], [mask]
-    for i in range(1, 8):
-        c, m, _ = latent(np.random.default_rng(3000 + i), G, H, W)
-        codes.append(c)
-        masks.append(m)
-    code8, mask8 = np.concatenate(codes, 0), np.concatenate(masks, 0)
-    fc, _ = codecs(shape, layers, imp_layers, batch=8)
-    streams = fc.encode(dev(code8), dev(mask8))
-    assert streams[0] == g["bytes"].tobytes()
-    monkeypatch.setenv("LIC360_DC", "16")
-    fc16, _ = codecs(shape, layers, imp_layers, batch=8)
-    assert np.array_equal(fc16.decode(streams, dev(mask8)).cpu().numpy(), code8 * mask8)

@@ -666,99 +666,6 @@ def test_context_layouts(lic):
     assert np.array_equal(host(lic.ContexShiftOp(True, 3, 0, False).forward(dev(sk))[0]), x)
 
 
-# ------------------------------------------------------------------ leaf-resident (4x4x1 MFMA) conv, direct C-ABI call
-@pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 7, 70), (6, 4, 4, True, True, 3, 3, 5, 66), (48, 4, 4, True, True, 3, 3, 3, 64),
-                                  (48, 4, 3, True, False, 3, 6, 4, 20), (48, 1, 4, False, True, 3, 3, 4, 130)],
-                         ids=lambda c: "g%d_%dto%d_%dx%d" % (c[0], c[1], c[2], c[7], c[8]))
-def test_cconv4_ec_bit_exact(lic, case):
-    import ctypes as C
-    G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = case_rng(case)
-    Cc, nout = G * cin, G * cout
-    w, b, a = conv_params(rng, nb, nout, Cc, act=act)
-    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
-    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
-    constrain = 6 if hidden else 5
-    ref = orc.cconv_ec(x, w, b, a, G, constrain) + res
-    L = lic._lib
-    plan = C.c_void_p(0)
-    assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
-    assert L.lic360_conv4_supported(plan) == 1
-    L.lic360_conv4_packed_floats.restype = C.c_long
-    L.lic360_conv4_packed_floats.argtypes = [C.c_void_p]
-    nper = L.lic360_conv4_packed_floats(plan)
-    packed = torch.empty(nb * nper, dtype=torch.float32, device="cuda:0")
-    xd, wd, bd, rd = dev(x), dev(w), dev(b), dev(res)
-    ad = dev(a) if act else None
-    out = torch.empty((N, nout, H, W), dtype=torch.float32, device="cuda:0")
-    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    assert L.lic360_conv4_pack(s, plan, P(wd), nb, P(packed)) == 0
-    assert L.lic360_cconv4_ec(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, N) == 0, L.lic360_last_error()
-    got = host(out)
-    L.lic360_conv_plan_destroy(plan)
-    assert np.array_equal(got, ref), "max abs diff %g" % np.abs(got - ref).max()
-
-
-def _ec6_maps(L, H, W):
-    import ctypes as C
-    rows, pitch, row0, wpp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    assert L.lic360_ec6_layout(H, W, C.byref(rows), C.byref(pitch), C.byref(row0), C.byref(wpp)) == 0
-    rows, pitch, row0, wpp = rows.value, pitch.value, row0.value, wpp.value
-    th, tw = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    sg = (th + tw + 2) % wpp
-    return rows, pitch, row0, wpp, th, tw, sg
-
-
-def _to_ec6(x, maps):
-    rows, pitch, row0, wpp, th, tw, sg = maps
-    out = np.zeros(x.shape[:2] + (rows, pitch), np.float32)
-    out[:, :, sg + row0, th + 2] = x
-    lo = sg < rows - wpp - row0
-    out[:, :, (sg + row0 + wpp)[lo], (th + 2)[lo]] = x[:, :, th[lo], tw[lo]]
-    hi = sg >= wpp - row0
-    out[:, :, (sg + row0 - wpp)[hi], (th + 2)[hi]] = x[:, :, th[hi], tw[hi]]
-    return out
-
-
-@pytest.mark.parametrize("case", [(6, 1, 4, False, True, 3, 3, 7, 70), (6, 4, 4, True, True, 3, 3, 5, 66), (48, 4, 4, True, True, 3, 3, 3, 64),
-                                  (48, 4, 3, True, False, 3, 6, 4, 20), (9, 4, 4, True, True, 1, 2, 64, 9), (7, 1, 4, False, False, 1, 1, 33, 40),
-                                  (5, 4, 4, True, True, 1, 1, 70, 9), (4, 4, 3, True, False, 1, 2, 130, 8), (4, 1, 4, False, True, 1, 1, 123, 7)],
-                         ids=lambda c: "g%d_%dto%d_%dx%d" % (c[0], c[1], c[2], c[7], c[8]))
-def test_cconv4_ec_diag_bit_exact(lic, case):
-    """encode-order conv on the wrapped diagonal-major layout (lic360_cconv4_ec_diag) == oracle, incl. the duplicated rows"""
-    import ctypes as C
-    G, cin, cout, hidden, act, nb, N, H, W = case
-    rng = case_rng(case)
-    Cc, nout = G * cin, G * cout
-    w, b, a = conv_params(rng, nb, nout, Cc, act=act)
-    x = rng.standard_normal((N, Cc, H, W)).astype(np.float32)
-    res = rng.standard_normal((N, nout, H, W)).astype(np.float32)
-    constrain = 6 if hidden else 5
-    ref = orc.cconv_ec(x, w, b, a, G, constrain) + res
-    L = lic._lib
-    maps = _ec6_maps(L, H, W)
-    plan = C.c_void_p(0)
-    assert L.lic360_conv_plan_create(Cc, G, nout, 5, constrain, C.byref(plan)) == 0
-    L.lic360_conv4_packed_floats.restype = C.c_long
-    L.lic360_conv4_packed_floats.argtypes = [C.c_void_p]
-    packed = torch.empty(nb * L.lic360_conv4_packed_floats(plan), dtype=torch.float32, device="cuda:0")
-    total = L.lic360_conv4_buffer_floats(2, N * nout, H, W)                            # planes + the slack band fetches may touch
-    tail = torch.zeros(total - N * nout * maps[0] * maps[1], dtype=torch.float32, device="cuda:0")
-    xd = torch.cat([dev(_to_ec6(x, maps)).flatten(), tail])
-    rd = torch.cat([dev(_to_ec6(res, maps)).flatten(), tail])
-    wd, bd = dev(w), dev(b)
-    ad = dev(a) if act else None
-    out = torch.zeros(total, dtype=torch.float32, device="cuda:0")
-    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    assert L.lic360_conv4_pack(s, plan, P(wd), nb, P(packed)) == 0
-    assert L.lic360_cconv4_ec_diag(s, plan, P(xd), P(packed), P(bd), P(ad), P(rd), P(out), N, H, W, nb, N) == 0, L.lic360_last_error()
-    got = host(out)[:N * nout * maps[0] * maps[1]].reshape(N, nout, maps[0], maps[1])
-    L.lic360_conv_plan_destroy(plan)
-    assert np.array_equal(got, _to_ec6(ref, maps)), "wrapped-diagonal output (with its repeated rows and zero padding) differs"
-
-
 def test_conv_ops_follow_weight_data_writes(lic):
     """`param.data.copy_()` does not bump `param._version` (the reference's own QUANT init writes that way): the packed-weight
     cache must not serve stale weights -- encode order repacks per call, decode order at the start of every sweep."""
@@ -1003,42 +910,25 @@ def test_cconv16_last_layer_with_fused_tables(lic, G, B, H, W):
         len(bad), B * G * H * W, bad[:4].tolist(), got[tuple(bad[0])].tolist(), want[tuple(bad[0])].tolist())
 
 
-# ------------------------------------------------------------------ decode-order conv on 16x16x4 MFMAs (input-stationary), direct C-ABI call
-@pytest.mark.parametrize("case", [(8, 4, True, True, 3, 3, 6, 9), (48, 4, True, True, 3, 48, 8, 16), (48, 3, True, False, 3, 6, 64, 20),
-                                  (12, 4, True, True, 1, 2, 64, 9), (4, 4, False, True, 1, 1, 33, 40), (8, 4, True, True, 1, 16, 40, 12),
-                                  (4, 3, True, False, 1, 32, 30, 6), (20, 2, True, True, 2, 34, 17, 3), (48, 4, True, True, 3, 48, 64, 7),
-                                  (16, 4, True, True, 1, 17, 50, 30)],
-                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
-def test_cconv16_dc_planes_bit_exact(lic, case):
-    _cconv16_dc_planes(lic, case, "lic360_cconv16_dc_plane")
-
-
-@pytest.mark.parametrize("case", [(48, 4, True, True, 3, 48, 8, 16), (48, 3, True, False, 3, 48, 64, 20), (12, 4, True, True, 1, 16, 64, 9),
-                                  (8, 4, True, True, 1, 48, 40, 12), (4, 3, True, False, 2, 96, 30, 6), (16, 4, True, True, 1, 32, 50, 30),
-                                  (8, 4, False, True, 3, 144, 33, 21)],
-                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
-def test_cconv16_dq_planes_bit_exact(lic, case):
-    """the class-sequential form (4-wave workgroups: two samples on 64 rows or four on 32-row windows per task, the lane classes one
-    after the other): 16 | samples per net; three samples per net and XCD (odd: a task with an idle slot), 6 (4 + 2), short and full diagonals"""
-    _cconv16_dc_planes(lic, case, "lic360_cconv16_dq_plane")
-
-
+# ------------------------------------------------------------------ decode-order conv of the latent nets, plane by plane, direct C-ABI call
 @pytest.mark.parametrize("case", [(12, 4, True, True, 2, 48, 40, 12), (12, 4, True, True, 1, 48, 64, 20), (6, 3, True, False, 3, 144, 18, 7),
-                                  (15, 4, False, True, 2, 32, 30, 30)],
+                                  (15, 4, False, True, 2, 32, 30, 30), (8, 4, True, True, 3, 3, 6, 9), (48, 4, True, True, 3, 48, 8, 16),
+                                  (48, 3, True, False, 3, 6, 64, 20), (4, 4, False, True, 1, 1, 33, 40), (4, 3, True, False, 2, 96, 30, 6),
+                                  (20, 2, True, True, 2, 34, 17, 3), (48, 4, True, True, 3, 48, 64, 7), (16, 4, True, True, 1, 17, 50, 30),
+                                  (8, 4, False, True, 3, 144, 33, 21)],
                          ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
 def test_cconv4_dc_planes_packed_bit_exact(lic, case):
     """the production decode kernel (4x4x1 MFMAs, lic360_cconv4_dc_plane) plane by plane with its sample packing: THREE samples per task on the
     corner diagonals that fit 14 rows (24 | samples per net: lanes 0..15 / 20..35 / 40..55, top and bottom windows), two per task where they
     fit 26 rows (16 | samples per net), both in one launch (48 per net), neither (the middle diagonals); every case has more than 128 three-group
-    tasks per launch (fewer switch the kernel to its one-group-per-task latency mode, which does not pack)"""
-    _cconv16_dc_planes(lic, case, "lic360_cconv4_dc_plane", ("lic360_conv4_supported", "lic360_conv4_packed_floats", "lic360_conv4_pack"))
+    tasks per launch (fewer switch the kernel to its one-group-per-task latency mode, which does not pack); from the fifth case on: few samples
+    (latency mode), odd sample counts, cout = 2 / 3, first-layer constraint, widths below 5, 64-row diagonals, 144 samples"""
+    _cconv4_dc_planes(lic, case, "lic360_cconv4_dc_plane", ("lic360_conv4_supported", "lic360_conv4_packed_floats", "lic360_conv4_pack"))
 
 
-def _cconv16_dc_planes(lic, case, entry, packfns=("lic360_conv16dc_supported", "lic360_conv16dc_packed_floats", "lic360_conv16dc_pack")):
-    """lic360_cconv16_dc_plane (hidden / last layers of the latent nets in decode order: MFMA columns = input rows of one input
-    anti-diagonal) on the lic360_dc4_layout: after every checked plane the persistent output equals the oracle's
-    (extension/cconv_dc_cuda.cu:313-398) + residual; covers one sample per task on 64 rows, two samples per task on 32 rows
-    (16 | samples per net), odd pairs, cout < 4, group counts that are no multiple of 3 (the kernel needs 4 | G), odd heights, w < 5"""
+def _cconv4_dc_planes(lic, case, entry, packfns):
+    """one decode-order layer of the latent nets on the lic360_dc4_layout, plane by plane: after every checked plane the persistent output
+    equals the oracle's (extension/cconv_dc_cuda.cu:313-398) + residual"""
     import ctypes as C
     G, cout, hidden, act, nb, N, H, W = case
     rng = np.random.default_rng(1000 + 7 * G + 131 * N + 17 * H + W)

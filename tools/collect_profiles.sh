@@ -1,10 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the rocprofv3 evidence behind profiles/rNN_* -- kernel stats of the default bench,
-# kernel stats of the encode / decode probes alone on the GPU (decode: the production 4x4x1 kernel and, with LIC360_DC=16, the
-# 16x16x4 kernel), and the FETCH_SIZE / WRITE_SIZE passes (each counter in its own run).
-# usage: tools/collect_profiles.sh r04      -> gpurun_out/prof_r04/...   (progress lines on stdout: the run takes ~12 minutes)
+# kernel stats of the encode / decode / importance-map probes alone on the GPU, and the FETCH_SIZE / WRITE_SIZE passes (each counter in its own run).
+# usage: tools/collect_profiles.sh r05      -> gpurun_out/prof_r05/...   (progress lines on stdout: the run takes ~12 minutes)
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -14,30 +13,24 @@ echo bench done
 export PB=48
 rocprofv3 --kernel-trace --stats -d $O/dc -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_probe.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/ec -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_probe.txt 2>&1
-export LIC360_DC=16
-rocprofv3 --kernel-trace --stats -d $O/dc16 -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc16_probe.txt 2>&1
-export LIC360_DC=q
-rocprofv3 --kernel-trace --stats -d $O/dcq -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dcq_probe.txt 2>&1
-unset LIC360_DC
+rocprofv3 --kernel-trace --stats -d $O/imp -o p --output-format csv -- python3 $R/tools/imp_probe.py > $O/imp_probe.txt 2>&1
 # the streaming ops at 32 images: kernel-only durations (the event timings of stream_ops.json include the shim's per-call overhead)
 SOB_BATCHES=32 rocprofv3 --kernel-trace --stats -d $O/sops -o p --output-format csv -- python3 $R/tools/stream_ops_bench.py > $O/stream_ops_32.json 2> $O/sops.err
 echo probes done
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $O/dc_$C -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_$C.txt 2>&1
   rocprofv3 --kernel-trace --pmc $C -d $O/ec_$C -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_$C.txt 2>&1
-  export LIC360_DC=16
-  rocprofv3 --kernel-trace --pmc $C -d $O/dc16_$C -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc16_$C.txt 2>&1
-  unset LIC360_DC
+  rocprofv3 --kernel-trace --pmc $C -d $O/imp_$C -o p --output-format csv -- python3 $R/tools/imp_probe.py > $O/imp_$C.txt 2>&1
   echo pmc $C done
 done
 echo pmc done
 cd $R
 python3 tools/pmc_traffic.py $O/pmc_traffic.json 48 $O/dc_FETCH_SIZE/p_counter_collection.csv $O/dc_WRITE_SIZE/p_counter_collection.csv \
     $O/ec_FETCH_SIZE/p_counter_collection.csv $O/ec_WRITE_SIZE/p_counter_collection.csv \
-    $O/dc16_FETCH_SIZE/p_counter_collection.csv $O/dc16_WRITE_SIZE/p_counter_collection.csv
+    $O/imp_FETCH_SIZE/p_counter_collection.csv $O/imp_WRITE_SIZE/p_counter_collection.csv
 python3 tools/stream_ops_bench.py > $O/stream_ops.json
 # keep only the summaries (the traces are hundreds of MB)
-for d in bench dc ec dc16 dcq; do cp $O/$d/p_kernel_stats.csv $O/${d}_kernel_stats.csv; done
+for d in bench dc ec imp; do cp $O/$d/p_kernel_stats.csv $O/${d}_kernel_stats.csv; done
 cp $O/sops/p_kernel_stats.csv $O/stream_ops_kernel_stats.csv
-rm -rf $O/bench $O/dc $O/ec $O/dc16 $O/dcq $O/sops $O/*_FETCH_SIZE $O/*_WRITE_SIZE
+rm -rf $O/bench $O/dc $O/ec $O/imp $O/sops $O/*_FETCH_SIZE $O/*_WRITE_SIZE
 ls -la $O

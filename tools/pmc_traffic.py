@@ -3,14 +3,14 @@ PB images, single stream) one --pmc FETCH_SIZE pass and one --pmc WRITE_SIZE pas
 both counters are in KB and count the L2's memory-side requests, Infinity-Cache hits included; on gfx950 FETCH_SIZE reports half of
 the bytes of 16-B-per-lane streaming reads, so it is doubled).  Keys are bench.py's kernel classes.
 
-usage: pmc_traffic.py out.json images  dc_fetch.csv dc_write.csv  ec_fetch.csv ec_write.csv [dc16_fetch.csv dc16_write.csv]"""
+usage: pmc_traffic.py out.json images  dc_fetch.csv dc_write.csv  ec_fetch.csv ec_write.csv [imp_fetch.csv imp_write.csv]"""
 import collections
 import csv
 import json
 import sys
 
-CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16dc", "dc_hidden_16x16x4"), ("k_cconv16s", "ec_hidden"), ("k_cconv16<4, false>", "ec_hidden"),
-           ("k_cconv16<4, true>", "ec_last"), ("k_cconv16<1, false>", "ec_first")]
+CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16s", "ec_hidden"), ("k_cconv16<4, false>", "ec_hidden"),
+           ("k_cconv16<4, true>", "ec_last"), ("k_cconv16<1, false>", "ec_first"), ("k_cconv144<1, true", "imp_dc"), ("k_cconv144<1, false", "imp_ec"), ("k_imp_dc_map", "imp_dc_fused")]
 out_json, images = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
 for path in sys.argv[3:]:
@@ -26,7 +26,7 @@ for path in sys.argv[3:]:
         for pat, cls in CLASSES:
             if k.startswith(pat):
                 res[cls][ctr] = {"kernel": k.split("(")[0], "launches": len(disp[k]), "per_launch_KB": tot[k] / len(disp[k])}
-doc = {"command": "PB=%d rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/{dc,ec}_probe.py (one encode + decodes of %d images, "
+doc = {"command": "PB=%d rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/{dc,ec,imp}_probe.py (one encode + decodes of %d images, "
                   "single stream; separate passes per counter)" % (images, images),
        "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); Infinity-Cache hits are included in both counters; "
                "dc_hidden averages the 10 hidden and the 1 last (cout = 3) launch of a plane, which run the same kernel"}
