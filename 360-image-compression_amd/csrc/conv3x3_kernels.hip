@@ -1,0 +1,209 @@
+// conv3x3_kernels.hip -- the 3x3 stride-1 convolutions of the analysis / synthesis transforms on sphere-apron maps,
+// hand-written for gfx950: the tile loader reads the SPHERE APRON BY INDEX (no padded copy, no SpherePad launch), the epilogue applies
+// bias + PReLU + the block's residual add, and the SphereTrim that follows every such convolution becomes the output window (cells outside
+// it are simply not computed).  Replaces, per layer, nn.Conv2d + SpherePad + nn.PReLU + SphereTrim (+ the residual add) of
+// /root/reference/test/model_zoo.py:45-62 (ResidualBlockV2), :8-23 (ResidualBlock.conv2), :64-94 (ResidualBlockDown.conv2),
+// :144-169 (ResidualBlockUp.conv1 / conv2); apron rule: extension/sphere_pad_cuda.cu:48-65.
+//
+// Arithmetic: fp32 throughout, v_mfma_f32_16x16x4_f32 (bit for bit a k-ordered fmaf chain of 4 terms); the summation order over
+// (input channel, tap) is this kernel's own -- a library convolution fixes none either -- so parity with the oracle's conv2d is to 1e-4.
+//
+// Mapping.  Implicit GEMM with M = output channels, N = positions, K = (input channel, tap).  A workgroup (8 waves, two per SIMD) owns
+// a 16 x 16 tile of output positions of one image and NQ * 48 output channels: wave (mq, nh) keeps 48 channels (3 MFMA row tiles) x
+// RW rows x 16 columns in 12 RW accumulator registers (96 at NQ = 4).  Input channels arrive in chunks of 16: their 18 x 18 halo tiles
+// go to a double-buffered LDS image by per-lane LDS-DMA (`global_load_lds_dword`: each lane fetches ONE cell from wherever the sphere
+// rule says it lives -- longitude wrap, pole rows reflected and mirrored -- so interior and apron cells cost the same), one chunk ahead;
+// one barrier per chunk (864 MFMAs per wave).  For a (4-channel group, kw) pair a wave reads RW + 2 B operands (one per input row:
+// output row r at tap row kh reads input row r + kh) and 9 A operands (3 kh x 3 row tiles, three 16-byte loads per lane from a stream
+// packed in exactly this order, one pair ahead) for 9 RW MFMAs: 0.26 operand fetches per MFMA.  LDS plane pitch 336 = 16 (mod 64)
+// banks: the four k-planes of a B read fall on disjoint bank quarters.
+#include "common.h"
+#include <cstdint>
+
+typedef float s3_f4 __attribute__((ext_vector_type(4)));
+
+#define S3_T 16                                      // tile rows = tile columns
+#define S3_CK 16                                     // input channels per LDS chunk
+#define S3_XR (S3_T + 2)                             // halo tile rows / columns
+#define S3_PL 336                                    // LDS floats per channel plane (18 * 18 = 324 + 12)
+#define S3_NDMA 11                                   // DMA instructions per wave and chunk (8 waves x 11 x 64 >= 16 * 336)
+#define S3_BUF (8 * S3_NDMA * 64)                    // LDS floats per chunk buffer
+#define S3_THREADS 512
+
+struct S3Args {
+    const float *x, *w, *bias, *slope, *res;
+    float *out;
+    int n, cin, cout, hp, wp;                        // x: [n][cin][hp][wp]; cout = output channels of this launch (all blocks)
+    int pad, sphere;                                 // sphere != 0: cells of the `pad`-wide apron are read from the interior by index
+    int ring;                                        // output window = rows [ring, hp - ring) x columns [ring, wp - ring) of the input grid
+    int ohp, owp, ooff;                              // out: [n][cout][ohp][owp], window cell (ph, pw) at (ph - ooff, pw - ooff)
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void s3_dma(unsigned voff, const float *sbase, unsigned lds_byte_addr) {
+    // LDS destination = M0 + lane * 4; M0 is written inside the statement (tests/test_asm_m0.py: the compiler itself never reads M0 here)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ const float *s3_uniform(const float *p) {       // the value IS wave-uniform; this tells the compiler
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const float *)(((unsigned long)hi << 32) | lo);
+}
+// padded cell (ph, pw) of a sphere map -> the padded cell that holds its value (interior cells map to themselves); sphere_pad_cuda.cu:48-65
+__device__ __forceinline__ void s3_sphere(int &ph, int &pw, int hp, int wp, int pad) {
+    const int H = hp - 2 * pad, W = wp - 2 * pad;
+    int th = ph - pad, tw = pw - pad;
+    tw = tw < 0 ? tw + W : (tw >= W ? tw - W : tw);
+    if (th < 0) { th = -1 - th; tw = W - 1 - tw; }
+    else if (th >= H) { th = 2 * H - 1 - th; tw = W - 1 - tw; }
+    ph = th + pad; pw = tw + pad;
+}
+
+// weights: [cout block of NQ * 48][cin / 4][kw][mq][j = 0..2][lane] x 4 floats; lane l = 16 k + i, element e = 4 j + t = 3 kh + mt (e < 9):
+// W[co = 48 mq + 16 mt + i][ci = 4 cg + k][kh][kw] -- the A operand of the MFMA for (kh, row tile mt)
+__global__ void k_sconv3x3_pack(const float *__restrict__ w, float *__restrict__ packed, int cin, int cout, int nq, long total) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        long r = idx >> 8;
+        const int j = (int)(r % 3); r /= 3;
+        const int mq = (int)(r % nq); r /= nq;
+        const int kw = (int)(r % 3); r /= 3;
+        const int cg = (int)(r % (cin / 4)), blk = (int)(r / (cin / 4));
+        const int e = 4 * j + t, kh = e / 3, mt = e - 3 * kh;
+        float v = 0.0f;
+        if (e < 9) {
+            const int co = blk * nq * 48 + 48 * mq + 16 * mt + (lane & 15), ci = 4 * cg + (lane >> 4);
+            v = w[(((long)co * cin + ci) * 3 + kh) * 3 + kw];
+        }
+        packed[idx] = v;
+    }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
+    constexpr int NR = 8 / NQ, RW = S3_T / NR;                              // row groups per workgroup, rows per wave
+    __shared__ float xs[2][S3_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mq = wave % NQ, nh = wave / NQ;
+    const int tpi = a.tiles_x * a.tiles_y, img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi, ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int tr0 = a.ring + ty * S3_T, tc0 = a.ring + tx * S3_T;           // input-grid cell of the tile's first output
+    const int blk = blockIdx.y, cblk = NQ * 48;
+    const long PLg = (long)a.hp * a.wp;
+    // ---- this lane's cells of a chunk's LDS image: LDS float q = (i * 8 + wave) * 64 + lane <-> (channel q / 336, halo row, halo column)
+    unsigned voff[S3_NDMA];
+#pragma unroll
+    for (int i = 0; i < S3_NDMA; ++i) {
+        const int q = (i * 8 + wave) * 64 + lane;
+        int ch = q / S3_PL, rem = q - ch * S3_PL;
+        if (ch >= S3_CK || rem >= S3_XR * S3_XR) { ch = 0; rem = 0; }      // pitch padding and the slack behind the last plane: any valid cell
+        const int r = rem / S3_XR, c = rem - r * S3_XR;
+        int ph = tr0 - 1 + r, pw = tc0 - 1 + c;
+        ph = ph < 0 ? 0 : (ph > a.hp - 1 ? a.hp - 1 : ph);                  // (only cells of outputs outside the window reach past the map)
+        pw = pw < 0 ? 0 : (pw > a.wp - 1 ? a.wp - 1 : pw);
+        if (a.sphere) s3_sphere(ph, pw, a.hp, a.wp, a.pad);
+        voff[i] = (unsigned)(((long)ch * PLg + (long)ph * a.wp + pw) * 4);
+    }
+    const float *xb = a.x + (long)img * a.cin * PLg;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const float *)&xs[0][0];
+    auto issue_dma = [&](int ck) __attribute__((always_inline)) {
+        const float *sb = s3_uniform(xb + (long)ck * S3_CK * PLg);
+        const unsigned lb = lds0 + (unsigned)((ck & 1) * S3_BUF + wave * 64) * 4u;
+#pragma unroll
+        for (int i = 0; i < S3_NDMA; ++i) s3_dma(voff[i], sb, lb + (unsigned)(i * 8 * 64 * 4));
+    };
+    const int nck = a.cin / S3_CK, niter = nck * 12;
+    const s3_f4 *wl = (const s3_f4 *)a.w + ((long)blk * (a.cin / 4) * 3 * NQ + mq) * 3 * 64 + lane;   // + (it * NQ) * 192 per (cg, kw) pair
+    auto load_a = [&](int it, s3_f4 (&A)[3]) __attribute__((always_inline)) {
+        const s3_f4 *p = wl + (long)it * NQ * 192;
+        A[0] = p[0]; A[1] = p[64]; A[2] = p[128];
+    };
+    s3_f4 acc[3][RW];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[m][r] = (s3_f4){0.f, 0.f, 0.f, 0.f};
+    issue_dma(0);
+    s3_f4 A[3];
+    load_a(0, A);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ck = 0; ck < nck; ++ck) {
+        if (ck + 1 < nck) issue_dma(ck + 1);
+        const float *xl = &xs[ck & 1][kq * S3_PL + nh * RW * S3_XR + col];
+#pragma unroll
+        for (int p = 0; p < 12; ++p) {                                      // (4-channel group, kw) pairs of the chunk
+            const int cg = p / 3, kw = p - 3 * cg;
+            s3_f4 An[3];
+            const int itn = ck * 12 + p + 1;
+            load_a(itn < niter ? itn : niter - 1, An);
+            float b[RW + 2];
+#pragma unroll
+            for (int j = 0; j < RW + 2; ++j) b[j] = xl[cg * 4 * S3_PL + j * S3_XR + kw];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const int e = 3 * kh + m;
+                        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[e >> 2][e & 3], b[r + kh], acc[m][r], 0, 0, 0);
+                    }
+            A[0] = An[0]; A[1] = An[1]; A[2] = An[2];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the next chunk's DMAs have landed (and the prefetched A operands)
+        __syncthreads();
+    }
+    // ---- epilogue: bias, PReLU, residual, store.  Accumulator m, row r, register v: channel 48 mq + 16 m + 4 kq + v, position (row, col)
+    const int pw = tc0 + col;
+    const long oPL = (long)a.ohp * a.owp;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int co = blk * cblk + 48 * mq + 16 * m + 4 * kq;
+        const s3_f4 bs = *(const s3_f4 *)(a.bias + co);
+        s3_f4 sl = {1.f, 1.f, 1.f, 1.f};
+        if (a.slope) sl = *(const s3_f4 *)(a.slope + co);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int ph = tr0 + nh * RW + r;
+            if (ph < a.hp - a.ring && pw < a.wp - a.ring) {
+                const long o = ((long)img * a.cout + co) * oPL + (long)(ph - a.ooff) * a.owp + (pw - a.ooff);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float y = acc[m][r][v] + bs[v];
+                    if (a.slope) y = y > 0.f ? y : y * sl[v];
+                    if (a.res) y = y + a.res[((long)img * a.cout + co + v) * PLg + (long)ph * a.wp + pw];
+                    a.out[o + v * oPL] = y;
+                }
+            }
+        }
+    }
+}
+
+static inline bool s3_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout >= 96 && (cout % 192 == 0 || cout == 96); }
+LIC360_API int lic360_sconv3x3_supported(int cin, int cout) { return s3_ok(cin, cout) ? 1 : 0; }
+LIC360_API long lic360_sconv3x3_packed_floats(int cin, int cout) { return s3_ok(cin, cout) ? (long)cout / 48 * (cin / 4) * 3 * 3 * 256 : 0; }
+LIC360_API int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int cin, int cout) {
+    ARG_CHECK(weight && packed && s3_ok(cin, cout));
+    const long total = lic360_sconv3x3_packed_floats(cin, cout);
+    hipLaunchKernelGGL(k_sconv3x3_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, cin, cout, cout % 192 == 0 ? 4 : 2, total);
+    LAUNCH_CHECK();
+    return 0;
+}
+LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
+                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int out_crop) {
+    ARG_CHECK(x && packed && bias && out && n > 0 && s3_ok(cin, cout) && pad >= 0 && ring >= 1 && hp > 2 * ring && wp > 2 * ring && out_crop >= 0 && out_crop <= ring);
+    ARG_CHECK(!sphere || (pad >= 1 && hp >= 4 * pad && wp >= 4 * pad));     // the wrapped / reflected source of an apron cell is an interior cell
+    ARG_CHECK((double)S3_CK * hp * wp * 4.0 < 4294967296.0 && ((uintptr_t)bias & 15) == 0 && (!slope || ((uintptr_t)slope & 15) == 0));
+    ARG_CHECK(!residual || out_crop == 0);                                  // the residual has the input's geometry
+    S3Args a;
+    a.x = x; a.w = packed; a.bias = bias; a.slope = slope; a.res = residual; a.out = out;
+    a.n = n; a.cin = cin; a.cout = cout; a.hp = hp; a.wp = wp; a.pad = pad; a.sphere = sphere; a.ring = ring;
+    a.ooff = out_crop; a.ohp = hp - 2 * out_crop; a.owp = wp - 2 * out_crop;
+    a.tiles_y = (hp - 2 * ring + S3_T - 1) / S3_T; a.tiles_x = (wp - 2 * ring + S3_T - 1) / S3_T;
+    const long tiles = (long)n * a.tiles_x * a.tiles_y;
+    ARG_CHECK(tiles < (1L << 31));
+    if (cout % 192 == 0) hipLaunchKernelGGL(k_sconv3x3<4>, dim3((unsigned)tiles, cout / 192), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_sconv3x3<2>, dim3((unsigned)tiles, 1), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return 0;
+}

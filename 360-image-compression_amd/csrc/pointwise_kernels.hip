@@ -191,6 +191,26 @@ LIC360_API int lic360_sphere_pad_inplace(void *stream, float *x, int nc, int hp,
     LAUNCH_CHECK();
     return 0;
 }
+// the apron of dst <- the sphere-wrapped interior of src (same geometry; src == dst is lic360_sphere_pad_inplace): what `x + SphereTrim(y)`
+// leaves in the apron of a block's output when x's apron had been refreshed (test/model_zoo.py:56-62) -- used behind lic360_sconv3x3
+__global__ __launch_bounds__(256) void k_sphere_apron_from_plane(const float *__restrict__ src, float *__restrict__ dst, int per_plane, int Hp, int Wp, int pad) {
+    const float *sp = src + (long)blockIdx.y * Hp * Wp;
+    float *dp = dst + (long)blockIdx.y * Hp * Wp;
+    const int H = Hp - 2 * pad, W = Wp - 2 * pad;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < per_plane; a += gridDim.x * 256) {
+        int ph, pw, th, tw;
+        apron_cell(a, Hp, Wp, pad, ph, pw);
+        sphere_src(ph, pw, H, W, pad, th, tw);
+        dp[ph * Wp + pw] = sp[(th + pad) * Wp + tw + pad];
+    }
+}
+LIC360_API int lic360_sphere_apron_from(void *stream, const float *src, float *dst, int nc, int hp, int wp, int pad) {
+    ARG_CHECK(src && dst && nc > 0 && nc <= 65535 && pad >= 1 && hp > 2 * pad && wp > 2 * pad && pad <= hp - 2 * pad && pad <= wp - 2 * pad && (long)hp * wp < (1l << 30));
+    const int per_plane = 2 * pad * wp + 2 * pad * (hp - 2 * pad);
+    hipLaunchKernelGGL(k_sphere_apron_from_plane, dim3(plane_chunks(per_plane, nc), nc), dim3(256), 0, (hipStream_t)stream, src, dst, per_plane, hp, wp, pad);
+    LAUNCH_CHECK();
+    return 0;
+}
 LIC360_API int lic360_sphere_trim(void *stream, float *x, int nc, int h, int w, int pad) {
     ARG_CHECK(x && nc > 0 && pad >= 0 && h >= 2 * pad && w >= 2 * pad);
     if (pad == 0) return 0;

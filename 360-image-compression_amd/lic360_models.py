@@ -3,16 +3,54 @@ into the (quantised latent, importance mask, importance map) triple the entropy 
 
 Architecture and parameter names follow the reference's inference models (test/model_zoo.py:8-205, 334-379) so that its checkpoints
 load with `load_state_dict`: the same module tree (`encoder.net.N...`, `decoder.net.N...`, `quant`, `imp`), built here from a few
-generic pieces.  The convolutions are library work (torch -> MIOpen, 105-116 nominal TFLOP/s for the 192-channel 3x3 layers on this
-GPU); what is native is everything around them: sphere pad / trim / cut-edge / pixel-shuffle / importance map /
-quantiser kernels of this package and the one-pass GDN (csrc/gdn_kernels.hip)."""
+generic pieces.  When no gradient is recorded, the 3x3 stride-1 convolutions of 96 / 192 channels on maps large enough to fill the chip run
+on this package's own kernel (csrc/conv3x3_kernels.hip, `lic360.sconv3x3`): fp32 MFMA, the sphere apron read by index in its tile loader
+(no in-place SpherePad in front of it), bias + PReLU + the residual add in its epilogue, the SphereTrim behind it as its output window.
+The stride-2 and 1x1 convolutions, small maps and every recording (training) pass are library work (torch -> MIOpen); native around them:
+sphere pad / trim / cut-edge / pixel-shuffle / importance map / quantiser kernels and the one-pass GDN (csrc/gdn_kernels.hip)."""
 import torch
 from torch import nn
+import lic360
 from lic360_operator import GDN, Dtow, SpherePad, SphereTrim, SphereCutEdge, QUANT, Dquant, SphereLatScaleNet, ImpMap
 
 
 def _conv(cin, cout, k, stride=1, pad=0):
     return nn.Conv2d(cin, cout, k, stride, pad)
+
+
+FUSED_MIN_WORKGROUPS = 768          # lic360.sconv3x3 is used from three workgroups per CU on (measured against MIOpen: tools/conv3x3_probe.py)
+
+
+def _fusable(conv, x, ring):
+    """does this 3x3 stride-1 convolution of a map with x's batch, height and width run on lic360.sconv3x3?  (inference only: the kernel has
+    no backward)"""
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None):
+        return False
+    cout, cin = conv.weight.shape[:2]
+    if not lic360.sconv3x3_supported(cin, cout):
+        return False
+    n, _, hp, wp = x.shape
+    tiles = n * ((hp - 2 * ring + 15) // 16) * ((wp - 2 * ring + 15) // 16) * (cout // 192 if cout % 192 == 0 else 1)
+    return tiles >= FUSED_MIN_WORKGROUPS
+
+
+def _packed(conv):
+    """the conv's weight in lic360.sconv3x3's operand order, repacked when the parameter was written (its version counter) or moved"""
+    key = (conv.weight.data_ptr(), conv.weight._version)
+    if getattr(conv, "_s3_key", None) != key:
+        conv._s3_packed, conv._s3_key = lic360.sconv3x3_pack(conv.weight.detach()), key
+    return conv._s3_packed
+
+
+def _scratch(mod, name, shape, like):
+    """a zero-initialised work buffer owned by the module (cells the kernels never write stay zero); never handed to the caller"""
+    buf = getattr(mod, name, None)
+    if buf is None or tuple(buf.shape) != tuple(shape) or buf.device != like.device:
+        buf = torch.zeros(shape, dtype=torch.float32, device=like.device)
+        setattr(mod, name, buf)
+    return buf
 
 
 class ResidualBlock(nn.Module):
@@ -27,6 +65,13 @@ class ResidualBlock(nn.Module):
         self.trim = SphereTrim(2, device_id)
 
     def forward(self, x):
+        if _fusable(self.conv2, x, 2):
+            # conv1 and PReLU are pointwise, so the apron of relu1(conv1(pad(x))) is the sphere wrap of its own interior: conv2 reads it
+            # by index and x needs no refresh; only the interior of conv2's output survives the final trim
+            y = self.relu1(self.conv1(x)).contiguous()
+            y2 = _scratch(self, "_s3_y2", y.shape, y)
+            lic360.sconv3x3(y, _packed(self.conv2), self.conv2.bias, self.relu2.weight, None, y2, pad=2, sphere=True, ring=2)
+            return self.trim(x + self.conv3(y2))
         y = self.pad(x)
         y = self.relu2(self.conv2(self.relu1(self.conv1(y))))
         return self.trim(x + self.conv3(y))
@@ -41,6 +86,8 @@ class AttentionBlock(nn.Module):
         self.attention = nn.Sequential(*three(), _conv(channels, channels, 1), nn.Sigmoid())
 
     def forward(self, x):
+        if _fusable(self.trunk[0].conv2, x, 2):
+            x = self.trunk[0].pad(x)                                       # the reference's first ResidualBlock refreshes x's apron in place: `x + ...` below carries it
         return x + self.trunk(x) * self.attention(x)
 
 
@@ -53,6 +100,14 @@ class ResidualBlockV2(nn.Module):
         self.conv2, self.relu2, self.trim2 = _conv(channels, channels, 3, 1, 1), nn.PReLU(channels), SphereTrim(2, device_id)
 
     def forward(self, x):
+        if _fusable(self.conv1, x, 1) and x.is_contiguous():
+            # conv1 over the apron read by index, output on the 1-ring window (the outermost ring is never read); conv2 reads that as it
+            # is, adds x on the interior; the output's apron is x's refreshed apron, as `x + trim2(...)` leaves it in the reference
+            y1 = _scratch(self, "_s3_y1", x.shape, x)
+            lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, y1, pad=2, sphere=True, ring=1)
+            out = torch.empty_like(x)
+            lic360.sconv3x3(y1, _packed(self.conv2), self.conv2.bias, self.relu2.weight, x, out, pad=2, sphere=False, ring=2)
+            return lic360.sphere_apron_from(x, out, 2)
         y = self.trim1(self.relu1(self.conv1(self.pad(x))))
         return x + self.trim2(self.relu2(self.conv2(y)))
 
@@ -77,8 +132,13 @@ class ResidualBlockDown(nn.Module):
         else:
             x = self.pad1(x)
             skip, y = None, x
-        y = self.pad2(self.trim(self.relu1(self.conv1(y))))
-        y = self.relu2(self.conv2(y))
+        y = self.trim(self.relu1(self.conv1(y)))
+        if _fusable(self.conv2, y, 2) and y.is_contiguous():
+            # conv2 reads the apron of y by index (no pad2); GDN is pointwise over positions, its frame cells are trimmed below
+            y2 = _scratch(self, "_s3_y2", y.shape, y)
+            y = self.relu2(lic360.sconv3x3(y, _packed(self.conv2), self.conv2.bias, None, None, y2, pad=2, sphere=True, ring=2))
+        else:
+            y = self.relu2(self.conv2(self.pad2(y)))
         return self.trim((self.short_cut(x) if skip is None else skip) + y)
 
 
@@ -133,7 +193,11 @@ class ResidualBlockUp(nn.Module):
 
     def forward(self, x):
         b = self.trim1(self.dtow1(self.relu1(self.conv1(self.pad1(x)))))
-        b = self.relu2(self.conv2(self.pad2(b)))
+        if _fusable(self.conv2, b, 2) and b.is_contiguous():
+            b2 = _scratch(self, "_s3_b2", b.shape, b)
+            b = self.relu2(lic360.sconv3x3(b, _packed(self.conv2), self.conv2.bias, None, None, b2, pad=2, sphere=True, ring=2))
+        else:
+            b = self.relu2(self.conv2(self.pad2(b)))
         return self.trim2(b + self.dtow2(self.short_cut(self.cut_edge(x))))
 
 

@@ -24,7 +24,7 @@ M0_WRITERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and _write
 
 
 def test_the_m0_writing_sources_are_the_known_ones():
-    assert M0_WRITERS == ["cconv144_kernels.hip", "cconv16_kernels.hip", "codec_fused.hip"], M0_WRITERS
+    assert M0_WRITERS == ["cconv144_kernels.hip", "cconv16_kernels.hip", "codec_fused.hip", "conv3x3_kernels.hip"], M0_WRITERS
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")

@@ -156,6 +156,71 @@ def test_blocks_match_the_oracle(lic):
             assert np.allclose(got, want, rtol=1e-4, atol=1e-4), "%s: max abs error %g" % (type(blk).__name__, err)
 
 
+@pytest.mark.parametrize("case", [(32, 96, 20, 36, 2, True, 0, True, True), (16, 192, 21, 37, 1, True, 0, True, False), (48, 192, 12, 20, 1, False, 1, True, False),
+                                  (32, 384, 18, 34, 2, False, 0, False, True), (64, 96, 9, 70, 1, True, 0, False, False)],
+                         ids=lambda c: "%dto%d_%dx%d_ring%d" % (c[0], c[1], c[2], c[3], c[4]))
+def test_sconv3x3_matches_the_oracle_conv(lic, case):
+    """lic360_sconv3x3 (csrc/conv3x3_kernels.hip: apron by index, bias + PReLU + residual in the epilogue, window = the trim) against the
+    oracle's restatement of what it replaces: in-place sphere pad -> conv2d -> PReLU -> (+ residual) on the window; cells outside the window
+    are not touched.  Odd sizes (ragged tiles), two output-channel blocks, the unpadded form (crop = 1), plain aprons (sphere = 0)."""
+    import oracle as orc
+    cin, cout, hp, wp, ring, sphere, crop, act, with_res = case
+    rng = np.random.default_rng(cin + 7 * cout + hp)
+    x = rng.standard_normal((2, cin, hp, wp)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    b, sl = rng.standard_normal(cout).astype(np.float32), rng.random(cout).astype(np.float32)
+    res = rng.standard_normal((2, cout, hp, wp)).astype(np.float32) if with_res else None
+    xin = orc.sphere_pad_inplace(x.copy(), 2) if sphere else x
+    want = orc.conv2d(xin, w, b, 1, 1 - crop)
+    if act:
+        want = orc.prelu(want, sl)
+    dev = lambda t: None if t is None else torch.from_numpy(t).cuda()
+    out = torch.full((2, cout, hp - 2 * crop, wp - 2 * crop), 7.0, device="cuda:0")
+    lic.sconv3x3(dev(x), lic.sconv3x3_pack(dev(w)), dev(b), dev(sl) if act else None, dev(res), out, pad=2, sphere=sphere, ring=ring, crop=crop)
+    got = out.cpu().numpy()
+    win = (slice(None), slice(None), slice(ring - crop, hp - crop - ring), slice(ring - crop, wp - crop - ring))
+    if with_res:
+        want = want + res
+    assert np.allclose(got[win], want[win], rtol=1e-4, atol=1e-4), float(np.abs(got[win] - want[win]).max())
+    frame = np.ones(got.shape, bool)
+    frame[win] = False
+    assert np.all(got[frame] == 7.0)
+
+
+def test_fused_blocks_match_the_oracle_at_full_width(lic, monkeypatch):
+    """the transform blocks at the reference's width (192 channels), where their 3x3 stride-1 convolutions run on lic360.sconv3x3 (forced
+    here for a small map), against the oracle's blocks: the whole output, aprons included"""
+    import oracle as orc
+    import lic360_models as lm
+    monkeypatch.setattr(lm, "FUSED_MIN_WORKGROUPS", 0)
+    torch.manual_seed(6)
+    c = 192
+    x = _refresh(torch.randn((1, c, 12, 20), device="cuda:0")).contiguous()
+    xn = x.cpu().numpy()
+    calls = []
+    real = lic.sconv3x3
+    monkeypatch.setattr(lic, "sconv3x3", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        for cls, fn, ncalls in ((lm.ResidualBlock, orc.blocks.residual, 1), (lm.ResidualBlockV2, orc.blocks.residual_v2, 2),
+                                (lambda ch, d: lm.ResidualBlockDown(ch, ch, d), orc.blocks.residual_down, 1), (lm.ResidualBlockUp, orc.blocks.residual_up, 1)):
+            blk = cls(c, 0).to("cuda:0")
+            for prm in blk.parameters():
+                if prm.dim() <= 2:
+                    prm.add_(0.05 * torch.rand_like(prm))
+            del calls[:]
+            got = blk(x.clone()).cpu().numpy()
+            assert len(calls) == ncalls, (type(blk).__name__, len(calls))
+            want = fn(xn.copy(), _block_params(blk))
+            assert np.allclose(got, want, rtol=1e-4, atol=1e-4), "%s: max abs error %g" % (type(blk).__name__, np.abs(got - want).max())
+        att = lm.AttentionBlock(c, 0).to("cuda:0")
+        monkeypatch.setattr(lm, "FUSED_MIN_WORKGROUPS", 1 << 30)
+        want = att(x.clone())                                                   # the library path of the same module
+        monkeypatch.setattr(lm, "FUSED_MIN_WORKGROUPS", 0)
+        del calls[:]
+        got = att(x.clone())
+        assert len(calls) == 6 and torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
+
+
 def test_state_dict_layout_is_the_references(lic):
     import lic360_models as lm
     enc, dec = lm.CMP_Encoder(32, 32, 8, 0), lm.CMP_Decoder(32, 32, 8, 0)
