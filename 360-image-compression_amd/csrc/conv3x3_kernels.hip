@@ -112,33 +112,49 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
         for (int i = 0; i < S3_NDMA; ++i) s3_dma(voff[i], sb, lb + (unsigned)(i * 8 * 64 * 4));
     };
     const int nck = a.cin / S3_CK, niter = nck * 12;
-    const s3_f4 *wl = (const s3_f4 *)a.w + ((long)blk * (a.cin / 4) * 3 * NQ + mq) * 3 * 64 + lane;   // + (it * NQ) * 192 per (cg, kw) pair
+    // A operands: asm loads + counted waits (hipcc sinks visible loads to just before their first use to save registers, which leaves their
+    // L2 latency exposed twice per pair; here the three 16-byte loads of pair it + 1 are issued at the top of pair it and waited for at the
+    // top of pair it + 1).  In-order counter: a chunk's 11 DMAs are issued BEHIND the A loads of its first pair, so `vmcnt(11)` at the second
+    // pair waits for the operands only and the DMAs have two pairs (~9000 cycles) before a `vmcnt(0)` asks for them.
+    const char *wl = (const char *)((const s3_f4 *)a.w + ((long)blk * (a.cin / 4) * 3 * NQ + mq) * 3 * 64 + lane);   // + it * NQ * 3072 bytes per (cg, kw) pair
     auto load_a = [&](int it, s3_f4 (&A)[3]) __attribute__((always_inline)) {
-        const s3_f4 *p = wl + (long)it * NQ * 192;
-        A[0] = p[0]; A[1] = p[64]; A[2] = p[128];
+        const char *p = wl + (long)it * (NQ * 3072);
+        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
+                     : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]) : "v"(p));
     };
+#define S3_WAIT_A(N, A_) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]))
     s3_f4 acc[3][RW];
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int r = 0; r < RW; ++r) acc[m][r] = (s3_f4){0.f, 0.f, 0.f, 0.f};
     issue_dma(0);
-    s3_f4 A[3];
-    load_a(0, A);
+    s3_f4 A[2][3];                                                          // operand sets by pair parity (12 pairs per chunk: the parity is static)
+    load_a(0, A[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ck = 0; ck < nck; ++ck) {
-        if (ck + 1 < nck) issue_dma(ck + 1);
         const float *xl = &xs[ck & 1][kq * S3_PL + nh * RW * S3_XR + col];
+        float b[2][RW + 2];
+#pragma unroll
+        for (int j = 0; j < RW + 2; ++j) b[0][j] = xl[j * S3_XR];            // pair 0 of the chunk (the later pairs are read one pair ahead)
 #pragma unroll
         for (int p = 0; p < 12; ++p) {                                      // (4-channel group, kw) pairs of the chunk
-            const int cg = p / 3, kw = p - 3 * cg;
-            s3_f4 An[3];
+            const int cur = p & 1, nxt = cur ^ 1;
+            if (p == 1) S3_WAIT_A(11, A[cur]);                              // (registers written by an asm load are only read behind the wait that names them)
+            else S3_WAIT_A(0, A[cur]);
             const int itn = ck * 12 + p + 1;
-            load_a(itn < niter ? itn : niter - 1, An);
-            float b[RW + 2];
+            load_a(itn < niter ? itn : niter - 1, A[nxt]);
+            if (p == 0 && ck + 1 < nck) issue_dma(ck + 1);
+            if (p == 0 && ck + 1 >= nck) {                                   // keep the count of the wait at p == 1 right: eleven harmless loads
 #pragma unroll
-            for (int j = 0; j < RW + 2; ++j) b[j] = xl[cg * 4 * S3_PL + j * S3_XR + kw];
+                for (int i = 0; i < S3_NDMA; ++i) s3_dma(voff[i], s3_uniform(xb), lds0 + (unsigned)(((ck & 1) ^ 1) * S3_BUF + (i * 8 + wave) * 64) * 4u);
+            }
+            if (p + 1 < 12) {
+                const int cgn = (p + 1) / 3, kwn = (p + 1) - 3 * cgn;
+#pragma unroll
+                for (int j = 0; j < RW + 2; ++j) b[nxt][j] = xl[cgn * 4 * S3_PL + j * S3_XR + kwn];
+            }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -146,22 +162,35 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const int e = 3 * kh + m;
-                        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[e >> 2][e & 3], b[r + kh], acc[m][r], 0, 0, 0);
+                        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][e >> 2][e & 3], b[cur][r + kh], acc[m][r], 0, 0, 0);
                     }
-            A[0] = An[0]; A[1] = An[1]; A[2] = An[2];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the next chunk's DMAs have landed (and the prefetched A operands)
         __syncthreads();
     }
+#undef S3_WAIT_A
     // ---- epilogue: bias, PReLU, residual, store.  Accumulator m, row r, register v: channel 48 mq + 16 m + 4 kq + v, position (row, col)
     const int pw = tc0 + col;
     const long oPL = (long)a.ohp * a.owp;
+    const float *__restrict__ resp = a.res;
+    float *__restrict__ outp = a.out;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const int co = blk * cblk + 48 * mq + 16 * m + 4 * kq;
         const s3_f4 bs = *(const s3_f4 *)(a.bias + co);
         s3_f4 sl = {1.f, 1.f, 1.f, 1.f};
         if (a.slope) sl = *(const s3_f4 *)(a.slope + co);
+        s3_f4 rv[RW];
+        if (resp) {                                                         // all residual loads of the row tile in flight before its first store
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int ph = tr0 + nh * RW + r;
+                const bool ok = ph < a.hp - a.ring && pw < a.wp - a.ring;
+                const long ri = ((long)img * a.cout + co) * PLg + (long)(ok ? ph : a.ring) * a.wp + (ok ? pw : a.ring);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rv[r][v] = resp[ri + v * PLg];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int ph = tr0 + nh * RW + r;
@@ -171,8 +200,8 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
                 for (int v = 0; v < 4; ++v) {
                     float y = acc[m][r][v] + bs[v];
                     if (a.slope) y = y > 0.f ? y : y * sl[v];
-                    if (a.res) y = y + a.res[((long)img * a.cout + co + v) * PLg + (long)ph * a.wp + pw];
-                    a.out[o + v * oPL] = y;
+                    if (resp) y = y + rv[r][v];
+                    outp[o + v * oPL] = y;
                 }
             }
         }
