@@ -10,7 +10,7 @@
 //
 // Mapping.  Implicit GEMM with M = output channels, N = positions, K = (input channel, tap).  A workgroup (8 waves, two per SIMD) owns
 // a 16 x 16 tile of output positions of one image and NQ * 48 output channels: wave (mq, nh) keeps 48 channels (3 MFMA row tiles) x
-// RW rows x 16 columns in 12 RW accumulator registers (96 at NQ = 4).  Input channels arrive in chunks of 16: their 18 x 18 halo tiles
+// RW rows x 16 columns in 12 RW accumulator registers (96 at NQ = 4, RW = 8).  Input channels arrive in chunks of 16: their 18 x 18 halo tiles
 // go to a double-buffered LDS image by per-lane LDS-DMA (`global_load_lds_dword`: each lane fetches ONE cell from wherever the sphere
 // rule says it lives -- longitude wrap, pole rows reflected and mirrored -- so interior and apron cells cost the same), one chunk ahead;
 // one barrier per chunk (864 MFMAs per wave).  For a (4-channel group, kw) pair a wave reads RW + 2 B operands (one per input row:
@@ -22,13 +22,13 @@
 
 typedef float s3_f4 __attribute__((ext_vector_type(4)));
 
-#define S3_T 16                                      // tile rows = tile columns
+#define S3_T 16                                      // tile columns (and rows of the main tile shape)
 #define S3_CK 16                                     // input channels per LDS chunk
-#define S3_XR (S3_T + 2)                             // halo tile rows / columns
-#define S3_PL 336                                    // LDS floats per channel plane (18 * 18 = 324 + 12)
-#define S3_NDMA 11                                   // DMA instructions per wave and chunk (8 waves x 11 x 64 >= 16 * 336)
-#define S3_BUF (8 * S3_NDMA * 64)                    // LDS floats per chunk buffer
+#define S3_XC (S3_T + 2)                             // halo tile columns
 #define S3_THREADS 512
+// tile shapes: TR rows x 16 columns.  LDS plane of a channel: (TR + 2) x 18 floats, pitch rounded up to 16 (mod 64) banks
+constexpr int s3_pitch(int tr) { int p = (tr + 2) * S3_XC; while (p % 64 != 16) ++p; return p; }   // TR = 16: 324 -> 336
+constexpr int s3_ndma(int tr) { return (S3_CK * s3_pitch(tr) + 511) / 512; }                      // DMA instructions per wave and chunk (8 waves x 64 lanes)
 
 struct S3Args {
     const float *x, *w, *bias, *slope, *res;
@@ -36,6 +36,7 @@ struct S3Args {
     int n, cin, cout, hp, wp;                        // x: [n][cin][hp][wp]; cout = output channels of this launch (all blocks)
     int pad, sphere;                                 // sphere != 0: cells of the `pad`-wide apron are read from the interior by index
     int ring;                                        // output window = rows [ring, hp - ring) x columns [ring, wp - ring) of the input grid
+    int rw, tall_last;                               // rows per wave of a tile; tall_last != 0: the last tile row runs rw + 1 rows per wave (the window's remainder rows)
     int ohp, owp, ooff;                              // out: [n][cout][ohp][owp], window cell (ph, pw) at (ph - ooff, pw - ooff)
     int tiles_x, tiles_y;
 };
@@ -79,14 +80,15 @@ __global__ void k_sconv3x3_pack(const float *__restrict__ w, float *__restrict__
     }
 }
 
-template <int NQ>
-__global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
-    constexpr int NR = 8 / NQ, RW = S3_T / NR;                              // row groups per workgroup, rows per wave
-    __shared__ float xs[2][S3_BUF];
+template <int NQ, int RW, int PD>                                           // NQ * 48 output channels per workgroup, RW rows per wave, A operands PD pairs ahead
+__device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int tx, int img) {
+    static_assert(12 % (PD + 1) == 0, "the operand ring's index must be static across chunks of 12 pairs");
+    constexpr int NR = 8 / NQ, TR = NR * RW;                                // row groups per workgroup, tile rows
+    constexpr int S3_PL = s3_pitch(TR), S3_NDMA = s3_ndma(TR), S3_BUF = 8 * S3_NDMA * 64, S3_XR = TR + 2;
+    float (*xs)[S3_BUF] = (float (*)[S3_BUF])lds;
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mq = wave % NQ, nh = wave / NQ;
-    const int tpi = a.tiles_x * a.tiles_y, img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi, ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-    const int tr0 = a.ring + ty * S3_T, tc0 = a.ring + tx * S3_T;           // input-grid cell of the tile's first output
+    const int tr0 = a.ring + ty * (NR * a.rw), tc0 = a.ring + tx * S3_T;    // input-grid cell of the tile's first output (a.rw: rows per wave of the ordinary tile rows)
     const int blk = blockIdx.y, cblk = NQ * 48;
     const long PLg = (long)a.hp * a.wp;
     // ---- this lane's cells of a chunk's LDS image: LDS float q = (i * 8 + wave) * 64 + lane <-> (channel q / 336, halo row, halo column)
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
     for (int i = 0; i < S3_NDMA; ++i) {
         const int q = (i * 8 + wave) * 64 + lane;
         int ch = q / S3_PL, rem = q - ch * S3_PL;
-        if (ch >= S3_CK || rem >= S3_XR * S3_XR) { ch = 0; rem = 0; }      // pitch padding and the slack behind the last plane: any valid cell
-        const int r = rem / S3_XR, c = rem - r * S3_XR;
+        if (ch >= S3_CK || rem >= S3_XR * S3_XC) { ch = 0; rem = 0; }      // pitch padding and the slack behind the last plane: any valid cell
+        const int r = rem / S3_XC, c = rem - r * S3_XC;
         int ph = tr0 - 1 + r, pw = tc0 - 1 + c;
         ph = ph < 0 ? 0 : (ph > a.hp - 1 ? a.hp - 1 : ph);                  // (only cells of outputs outside the window reach past the map)
         pw = pw < 0 ? 0 : (pw > a.wp - 1 ? a.wp - 1 : pw);
@@ -122,38 +124,42 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
         asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
                      : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]) : "v"(p));
     };
-#define S3_WAIT_A(N, A_) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]))
+#define S3_WAIT_A(N, A_) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]) : "n"(N))
     s3_f4 acc[3][RW];
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int r = 0; r < RW; ++r) acc[m][r] = (s3_f4){0.f, 0.f, 0.f, 0.f};
     issue_dma(0);
-    s3_f4 A[2][3];                                                          // operand sets by pair parity (12 pairs per chunk: the parity is static)
-    load_a(0, A[0]);
+    // operand ring: PD + 1 sets, pair `it` in set it % (PD + 1).  The wide tiles run one pair ahead (a pair is 72 MFMAs = 2304 cycles per wave);
+    // the 2-row remainder tiles have 9 MFMAs per pair and would wait a full L2 round trip per pair: they run five ahead.
+    s3_f4 A[PD + 1][3];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) load_a(d < niter ? d : niter - 1, A[d]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int ck = 0; ck < nck; ++ck) {
-        const float *xl = &xs[ck & 1][kq * S3_PL + nh * RW * S3_XR + col];
+        const float *xl = &xs[ck & 1][kq * S3_PL + nh * RW * S3_XC + col];
         float b[2][RW + 2];
 #pragma unroll
-        for (int j = 0; j < RW + 2; ++j) b[0][j] = xl[j * S3_XR];            // pair 0 of the chunk (the later pairs are read one pair ahead)
+        for (int j = 0; j < RW + 2; ++j) b[0][j] = xl[j * S3_XC];            // pair 0 of the chunk (the later pairs are read one pair ahead)
 #pragma unroll
         for (int p = 0; p < 12; ++p) {                                      // (4-channel group, kw) pairs of the chunk
-            const int cur = p & 1, nxt = cur ^ 1;
-            if (p == 1) S3_WAIT_A(11, A[cur]);                              // (registers written by an asm load are only read behind the wait that names them)
-            else S3_WAIT_A(0, A[cur]);
-            const int itn = ck * 12 + p + 1;
-            load_a(itn < niter ? itn : niter - 1, A[nxt]);
+            const int cur = p & 1, nxt = cur ^ 1, sa = p % (PD + 1), sn = (p + PD) % (PD + 1);
+            // in-order counter: behind set sa's loads came PD - 1 younger sets and -- for the PD pairs that follow a chunk's first -- its DMAs
+            if (p >= 1 && p <= PD) S3_WAIT_A(3 * (PD - 1) + S3_NDMA, A[sa]);  // (registers written by an asm load are only read behind the wait that names them)
+            else S3_WAIT_A(3 * (PD - 1), A[sa]);
+            const int itn = ck * 12 + p + PD;
+            load_a(itn < niter ? itn : niter - 1, A[sn]);
             if (p == 0 && ck + 1 < nck) issue_dma(ck + 1);
-            if (p == 0 && ck + 1 >= nck) {                                   // keep the count of the wait at p == 1 right: eleven harmless loads
+            if (p == 0 && ck + 1 >= nck) {                                   // keep the counts of the waits at p = 1 .. PD right: harmless loads into the idle buffer
 #pragma unroll
                 for (int i = 0; i < S3_NDMA; ++i) s3_dma(voff[i], s3_uniform(xb), lds0 + (unsigned)(((ck & 1) ^ 1) * S3_BUF + (i * 8 + wave) * 64) * 4u);
             }
             if (p + 1 < 12) {
                 const int cgn = (p + 1) / 3, kwn = (p + 1) - 3 * cgn;
 #pragma unroll
-                for (int j = 0; j < RW + 2; ++j) b[nxt][j] = xl[cgn * 4 * S3_PL + j * S3_XR + kwn];
+                for (int j = 0; j < RW + 2; ++j) b[nxt][j] = xl[cgn * 4 * S3_PL + j * S3_XC + kwn];
             }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const int e = 3 * kh + m;
-                        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cur][e >> 2][e & 3], b[cur][r + kh], acc[m][r], 0, 0, 0);
+                        acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[sa][e >> 2][e & 3], b[cur][r + kh], acc[m][r], 0, 0, 0);
                     }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the next chunk's DMAs have landed (and the prefetched A operands)
@@ -208,6 +214,17 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
     }
 }
 
+// A window of 16 k + 2 rows (every 1-ring window of these maps) would need a seventeenth tile row with 14 dead rows; instead its LAST tile row
+// runs one more row per wave (18 rows at 192 channels, 20 at 96): the workgroup picks its body by its tile row (uniform per workgroup).
+template <int NQ, int RW>
+__global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
+    constexpr int NR = 8 / NQ;
+    __shared__ float lds[2 * 8 * s3_ndma(NR * (RW + 1)) * 64];
+    const int tpi = a.tiles_x * a.tiles_y, img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi, ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    if (a.tall_last && ty == a.tiles_y - 1) s3_body<NQ, RW + 1, 1>(a, lds, ty, tx, img);
+    else s3_body<NQ, RW, 1>(a, lds, ty, tx, img);
+}
+
 static inline bool s3_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout >= 96 && (cout % 192 == 0 || cout == 96); }
 LIC360_API int lic360_sconv3x3_supported(int cin, int cout) { return s3_ok(cin, cout) ? 1 : 0; }
 LIC360_API long lic360_sconv3x3_packed_floats(int cin, int cout) { return s3_ok(cin, cout) ? (long)cout / 48 * (cin / 4) * 3 * 3 * 256 : 0; }
@@ -228,11 +245,15 @@ LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed
     a.x = x; a.w = packed; a.bias = bias; a.slope = slope; a.res = residual; a.out = out;
     a.n = n; a.cin = cin; a.cout = cout; a.hp = hp; a.wp = wp; a.pad = pad; a.sphere = sphere; a.ring = ring;
     a.ooff = out_crop; a.ohp = hp - 2 * out_crop; a.owp = wp - 2 * out_crop;
-    a.tiles_y = (hp - 2 * ring + S3_T - 1) / S3_T; a.tiles_x = (wp - 2 * ring + S3_T - 1) / S3_T;
+    a.tiles_x = (wp - 2 * ring + S3_T - 1) / S3_T;
+    const int nq = cout % 192 == 0 ? 4 : 2, nrg = 8 / nq, nr = hp - 2 * ring, full = nr / S3_T, rem = nr - full * S3_T;
+    a.rw = S3_T / nrg;
+    a.tall_last = rem > 0 && rem <= nrg && full > 0;                        // the remainder fits one more row per wave of the last tile row
+    a.tiles_y = a.tall_last ? full : (nr + S3_T - 1) / S3_T;
     const long tiles = (long)n * a.tiles_x * a.tiles_y;
     ARG_CHECK(tiles < (1L << 31));
-    if (cout % 192 == 0) hipLaunchKernelGGL(k_sconv3x3<4>, dim3((unsigned)tiles, cout / 192), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_sconv3x3<2>, dim3((unsigned)tiles, 1), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    if (nq == 4) hipLaunchKernelGGL((k_sconv3x3<4, 8>), dim3((unsigned)tiles, cout / 192), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_sconv3x3<2, 4>), dim3((unsigned)tiles, 1), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return 0;
 }
