@@ -15,7 +15,7 @@ ent.mean_net.*`, `imp_ent.net.*`) and pushed through the reference's cast_* func
 [weight, sigma, mu] batch order are the reference's, not ours.
 
 tests/test_driver_golden.py (CPU: tests/ref_codec.py; -m gpu: the op-level drivers and the fused codecs) must reproduce the files.
-usage: python3 oracle/gen_golden_drivers.py            (needs /root/reference, oracle/liblic360_oracle.so; ~1 min)
+usage: python3 oracle/gen_golden_drivers.py [a b c]    (needs /root/reference, oracle/liblic360_oracle.so; cases a, b ~1 min, c ~10 min)
 """
 import os
 import sys
@@ -124,7 +124,11 @@ def main():
         return cpu_keys(drv)
 
     # ---- case A: the demo's own flow at G = 48 on a small ERP: importance map -> its bitstream -> decoded mask -> latent bitstream
-    for tag, G, H, W, seed in (("a", 48, 8, 12, 4101), ("b", 48, 6, 10, 4102)):
+    # case c (round 5): 64 rows -- full-lane diagonals of the decode kernels, 64-row windows, corner diagonals that pack two / three samples per task
+    only = set(sys.argv[1:])
+    for tag, G, H, W, seed in (("a", 48, 8, 12, 4101), ("b", 48, 6, 10, 4102), ("c", 48, 64, 20, 4103)):
+        if only and tag not in only:
+            continue
         wseed = 1000 + seed
         layers, imp_layers = make_main_params(wseed, G), make_imp_params(wseed)
         code, mask, levels = latent(np.random.default_rng(seed), G, H, W)

@@ -28,6 +28,9 @@
 #include <math.h>
 
 #include "../360-image-compression_amd/csrc/lic360_exact_math.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -65,6 +68,17 @@ ORC_API int orc_plane_len(int psum, int G, int H, int W, const int *plane_idx) {
     if (psum < 0 || psum >= H + W + G - 2) return 0;
     plane_window(psum, G, H, W, plane_idx, &s, &l);
     return l;
+}
+
+/* thread pool of the OpenMP loops below (bench.py's cpu_baseline leg times the oracle at the GPU's share of the host cores and at all of them) */
+ORC_API int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 /* ------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ def load(path):
 
 
 def test_golden_files_exist():
-    assert len(GOLD) >= 2
+    assert len(GOLD) >= 3
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
@@ -86,3 +86,11 @@ def test_hip_drivers_reproduce_the_reference_drivers(tmp_path, path):
     fic.load_layers(imp_layers)
     assert fic.encode(dev(levels))[0] == imp
     assert np.array_equal(fic.decode([imp]).cpu().numpy(), levels)
+    if H >= 28:
+        # the 64-row golden as a batch of 16 copies: more than 128 three-group tasks per launch, so the decode kernel leaves its latency mode and
+        # runs its throughput schedule -- full-lane diagonals, two samples per task on the corner diagonals (16 | samples per net)
+        fcb = FusedCodec(G, H, W, max_batch=16)
+        fcb.load_layers(layers)
+        rep = lambda a: np.ascontiguousarray(np.repeat(a, 16, 0))
+        assert fcb.encode(dev(rep(code)), dev(rep(mask))) == [lat] * 16
+        assert np.array_equal(fcb.decode([lat] * 16, dev(rep(g["decoded_mask"]))).cpu().numpy(), rep(g["decoded_code"]))
