@@ -542,6 +542,25 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
         rows.append(row)
     convs = [r for r in rows if r["bound"] == "mfma"]
     dom = max(convs, key=lambda r: r["total_ms"])
+    # the importance-map stream of the same sub-batch, alone on the GPU: whole passes (12 conv layers of the one-group 144-channel net -- layer 0
+    # on the generic kernel, 1..11 on k_cconv144 --, 49-way tables, coder; decode: 95 planes x 13 launches), wall time between synchronisations
+    ic0, lv0 = icodecs[0], levels[0]
+    for name, fn in (("imp_ec", lambda: ic0.encode_async(lv0)), ("imp_dc", lambda: ic0.decode_async(b0))):
+        with torch.cuda.stream(streams[0]):
+            fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        fl = 2 * IMP_GMAC * 1e9 * b0
+        rows.append({"kernel": name, "launches": 1, "avg_launch_ms": ms, "images_per_launch": b0, "total_ms": ms, "bound": "mfma",
+                     "achieved": fl / (ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                     "algorithmic_flops_per_launch": fl,
+                     "note": "whole pass of the importance-map %s of %d maps (all conv layers + tables + coder), wall time; %s" % (
+                         "encode" if name == "imp_ec" else "decode", b0,
+                         "one launch per layer" if name == "imp_ec" else "95 planes x 13 dependent launches: launch-latency bound")})
     # fabric-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/collect_profiles.sh;
     # Infinity-Cache hits are counted), scaled to this run's images per launch
     pmc, pmc_file = newest_pmc_traffic()

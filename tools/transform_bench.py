@@ -54,6 +54,22 @@ def measure(batch=8, device=0, reps=3):
                      "achieved": fl / t_f / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / t_f / 1e12 / F32_PEAK_TFLOPS,
                      "algorithmic_bytes_per_launch": 2.0 * x.numel() * 4, "GBps": 2.0 * x.numel() * 4 / t_f / 1e9,
                      "torch_four_kernel_form_ms": t_t * 1e3, "speedup_vs_torch": t_t / t_f})
+        # the hand-written 3x3 convolution (csrc/conv3x3_kernels.hip) on the two shapes that carry the transforms, against the library convolution alone
+        # and against the library form of everything the kernel does (in-place apron refresh + conv + PReLU + trim + residual add)
+        for hp, wp in ((260, 516), (132, 260)):
+            xx = torch.randn((batch, c, hp, wp), device=dev)
+            ww, bb, sl = torch.randn((c, c, 3, 3), device=dev) * 0.05, torch.randn((c,), device=dev), torch.rand((c,), device=dev) * 0.5
+            res, oo, pk = torch.randn_like(xx), torch.zeros_like(xx), lic360.sconv3x3_pack(ww)
+            pad_op, trim_op = lic360.SpherePadOp(2, True, device, False), lic360.SphereTrimOp(2, device, False)
+            t_o = timed(lambda: lic360.sconv3x3(xx, pk, bb, sl, res, oo, pad=2, sphere=True, ring=2), 5)
+            t_c = timed(lambda: F.conv2d(xx, ww, bb, padding=1), 5)
+            t_l = timed(lambda: trim_op.forward(F.prelu(F.conv2d(pad_op.forward(xx)[0], ww, bb, padding=1), sl))[0] + res, 5)
+            fl = 2.0 * batch * c * c * 9 * (hp - 4) * (wp - 4)
+            rows.append({"kernel": "sconv3x3 192->192 on %dx%d maps (%dx%d window): apron by index + conv + bias + PReLU + trim + residual" % (hp, wp, hp - 4, wp - 4),
+                         "bound": "mfma", "images_per_launch": batch, "avg_launch_ms": t_o * 1e3, "achieved": fl / t_o / 1e12, "peak": F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": fl / t_o / 1e12 / F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl,
+                         "miopen_conv_alone_ms": t_c * 1e3, "miopen_conv_with_pad_prelu_trim_add_ms": t_l * 1e3,
+                         "speedup_vs_miopen_conv_alone": t_c / t_o, "speedup_vs_library_form": t_l / t_o})
     rows.append(whole_codec(enc, dec, device))
     return rows
 
