@@ -32,6 +32,8 @@ import os
 import sys
 import time
 
+T_START = time.time()
+
 # Six HIP streams per rank (three sub-batches x {latent codec, importance-map codec}).  The HIP runtime multiplexes streams over 4
 # hardware queues by default: an importance stream that shares a queue with a latent stream runs behind that stream's long kernels,
 # and the latent decodes gated on it (lic360_codec_decode_gated) stall -- 49.3 instead of 50.6 Mpixel/s.  Must be set before the
@@ -99,30 +101,38 @@ def synth_latents(batch, seed0, h=H, w=W):
 
 def cpu_baseline(layers, imp_layers, code, mask, levels, gpu_bytes, gpu_imp_bytes):
     """The CPU oracle (oracle/, test infrastructure) on ONE WHOLE image: encode + decode of both streams, OpenMP over the (sample, output
-    channel) planes of each layer -- timed twice: on ALL host cores of the box (`value`, `cores`) and on this GPU's share of
-    them (16 threads: `share16`).  Also the checker of the timed data: the GPU's bitstreams of this image must equal the oracle's."""
+    channel) planes of each layer, on this GPU's share of the box's host cores (16 threads: `value`, `cores`).  Beside it the ENCODE direction
+    alone on ALL host cores (`all_cores`): the box is shared between its GPUs' jobs, and the decode direction -- 8 568 small
+    parallel regions, one per layer and plane -- does not scale on cores other jobs are using (round 4: the whole leg took 75 s on 256 threads
+    against 35 s on 16).  Also the checker of the timed data: the GPU's bitstreams of this image must equal the oracle's."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import ref_codec as rc
     import oracle as orc
     nproc, cpu_model = host_cpu()
-    legs = {}
-    for threads in sorted({min(16, nproc), nproc}):
-        cores = int(orc.lib.orc_set_num_threads(threads))
-        t0 = time.time()
-        data = rc.encode_main(code, mask, layers, G)
-        imp = rc.encode_imp(levels, imp_layers)
-        t1 = time.time()
-        out = rc.decode_main(data, mask, layers, G)
-        lv = rc.decode_imp(imp, imp_layers, H // 2, W // 2)
-        t2 = time.time()
-        assert np.array_equal(out, code * mask) and np.array_equal(lv, levels)
-        same = bool(data == gpu_bytes and imp == gpu_imp_bytes)
-        assert same, "GPU bitstream of image 0 differs from the oracle's"
-        legs[cores] = (t0, t1, t2)
-    cores = max(legs)
-    t0, t1, t2 = legs[cores]
-    s0, s1, s2 = legs[min(legs)]
+    cores = int(orc.lib.orc_set_num_threads(min(16, nproc)))
+    progress("cpu_baseline: oracle encode + decode of one image on %d threads" % cores)
+    t0 = time.time()
+    data = rc.encode_main(code, mask, layers, G)
+    imp = rc.encode_imp(levels, imp_layers)
+    t1 = time.time()
+    progress("cpu_baseline: encode %.1f s; decode ..." % (t1 - t0))
+    out = rc.decode_main(data, mask, layers, G)
+    lv = rc.decode_imp(imp, imp_layers, H // 2, W // 2)
+    t2 = time.time()
+    assert np.array_equal(out, code * mask) and np.array_equal(lv, levels)
+    same = bool(data == gpu_bytes and imp == gpu_imp_bytes)
+    assert same, "GPU bitstream of image 0 differs from the oracle's"
+    all_cores = None
+    if nproc > cores:
+        n_all = int(orc.lib.orc_set_num_threads(nproc))
+        progress("cpu_baseline: oracle encode on all %d host threads" % n_all)
+        a0 = time.time()
+        same_all = rc.encode_main(code, mask, layers, G) == data and rc.encode_imp(levels, imp_layers) == imp
+        a1 = time.time()
+        orc.lib.orc_set_num_threads(cores)
+        all_cores = {"cores": n_all, "encode_s": a1 - a0, "encode_speedup_vs_%d_threads" % cores: (t1 - t0) / (a1 - a0), "bytes_equal": bool(same_all),
+                     "note": "encode direction only (36 + 12 layer-sized parallel loops); the box's cores are shared with other jobs"}
     # BASELINE.json configs[0] beside it: the range coder alone, one thread, 393 216 symbols (= 32 x 64 x 192) on the fixed 9-entry CDF
     rng = np.random.default_rng(1234)
     cdf = np.array([0, 1200, 5200, 14000, 32768, 51536, 60336, 64336, 65536], np.int32)
@@ -142,10 +152,15 @@ def cpu_baseline(layers, imp_layers, code, mask, levels, gpu_bytes, gpu_imp_byte
             "coder_single_thread": {"symbols": int(sym.size), "bytes": len(blob), "encode_Msym_per_s": sym.size / (c1 - c0) / 1e6,
                                     "decode_Msym_per_s": sym.size / (c2 - c1) / 1e6, "note": "configs[0]: range coder only, fixed CDF, one host thread"},
             "encode_s": t1 - t0, "decode_s": t2 - t1, "gpu_bytes_equal_oracle_bytes": same,
-            "share16": {"cores": min(legs), "value": PIXELS / (s2 - s0) / 1e6, "encode_s": s1 - s0, "decode_s": s2 - s1,
-                        "note": "the same leg on the per-GPU share of the host cores (16 threads)"},
+            "all_cores": all_cores,
             "sample": "oracle encode + decode of ONE whole 512x1024 image of the timed batch (image 0: latent 48x64x128 + 32x64 importance "
                       "map, full 12-layer x3 model), %.1f s on %d threads" % (t2 - t0, cores)}
+
+
+def progress(msg):
+    """one line on stderr per stage (a GPU box kills a command that writes nothing for seven minutes)"""
+    sys.stderr.write("[bench %6.1f s] %s\n" % (time.time() - T_START, msg))
+    sys.stderr.flush()
 
 
 def host_cpu():
@@ -290,6 +305,8 @@ def run_rank(args):
                 ok = ok and bool(torch.equal(ic.levels_out[:n], lv)) and int(ic.err[:n].abs().sum().item()) == 0 and mb is not None and bool(torch.equal(mb[:n], mk))
         return ok
 
+    say = progress if rank == 0 else (lambda m: None)
+    say("codecs ready; warm-up + %d timed steps of %d images" % (args.steps, B))
     step = lambda: run(codes, masks, levels, True)
     for _ in range(args.warmup):
         step()
@@ -301,6 +318,7 @@ def run_rank(args):
     inbytes = np.concatenate([c.nbytes[:cd.shape[0]].cpu().numpy() for c, cd in zip(icodecs, codes)])
     img0 = (bytes(codecs[0].bytes[0, :int(nbytes[0])].cpu().numpy().tobytes()), bytes(icodecs[0].bytes[0, :int(inbytes[0])].cpu().numpy().tobytes()))
 
+    say("timed region done: %.1f ms per step" % (dt / args.steps * 1e3))
     extras = {}
     if not args.no_extras:
         # the latent stream alone (98.6 % of the bytes, 95 % of the MACs): round 1's headline, kept for comparison
@@ -339,6 +357,7 @@ def run_rank(args):
         # BASELINE.json configs[4]: LIC3602K 1024x2048 ERPs (48x128x256 latents, 32x64 -> 64x128 importance maps), model-idx 7 seed,
         # 16 images per stream through codecs of their own (decode order runs on 64-row windows there, DESIGN.md 4.1 b)
         # (set-up may fail on one rank only, e.g. out of memory: the collective steps below run on every rank or on none)
+        say("config 4 figures done; config 5 (1024x2048 ERPs)")
         H5, W5, B5 = 2 * H, 2 * W, 16
         c5 = i5 = cd5 = mk5 = lv5 = None
         err5 = None
@@ -420,11 +439,13 @@ def run_rank(args):
         if "value" in extras.get("config5", {}):
             flat["config5_mpixel_s"], flat["config5_ms"] = extras["config5"]["value"], extras["config5"]["ms"]
         out["config"].update(extras)
+        say("instrumented passes (per-kernel-class events)")
         out.update(instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B))
         if world == 1 and not args.no_extras:
             si = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], istreams[0], mbufs[0][0], dev)
             out["config"]["single_image"] = si
             out["config"]["single_encode_ms"], out["config"]["single_decode_ms"] = si["encode_ms"], si["decode_ms"]
+            say("single image done; streaming ops")
             try:
                 import stream_ops_bench
                 rows = stream_ops_bench.measure(batches=(32,), device=local)
@@ -433,6 +454,7 @@ def run_rank(args):
             except Exception as e:                                     # noqa: BLE001  (never lose the headline to a side table)
                 out["config"]["streaming_ops_error"] = repr(e)
             try:       # the neighbouring row f1: analysis / synthesis transforms (library convs + native ops) and the one-pass GDN
+                say("transforms + whole codec")
                 import transform_bench
                 out["kernels"] += transform_bench.measure(batch=8, device=local)
             except Exception as e:                                     # noqa: BLE001
