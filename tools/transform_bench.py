@@ -74,12 +74,11 @@ def measure(batch=8, device=0, reps=3):
     return rows
 
 
-def whole_codec(enc, dec, device, batch=48, reps=2, nstreams=3):
-    """image -> analysis -> both entropy encoders -> bitstreams (in HBM) -> both entropy decoders -> synthesis -> image, seeded weights: the
-    end-to-end rate of the codec on one GPU.  The batch runs as `nstreams` independent sub-batches on HIP streams of their own (as bench.py runs
-    the entropy path): one sub-batch's launch-bound decode planes and serial coder chains fill under another's transforms.  Every stream has its
-    own copy of the networks (the fused blocks keep per-module work buffers) and its own codecs."""
-    import copy
+def whole_codec(enc, dec, device, batch=48, reps=2):
+    """image -> analysis -> both entropy encoders -> bitstreams (in HBM) -> both entropy decoders -> synthesis -> image, one stream, seeded
+    weights: the end-to-end rate of the codec on one GPU.  (Round 5 measured the same 48 images as three sub-batches of 16 on three streams with
+    their own copies of the networks: 19.7 Mpixel/s against 23.7 -- sixteen images per entropy-coder batch lose the decode kernels' sample packing
+    and the transforms gain nothing from running beside each other.)"""
     import time
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -87,48 +86,38 @@ def whole_codec(enc, dec, device, batch=48, reps=2, nstreams=3):
     from lic360_fused import FusedCodec, FusedImpCodec
     dev = "cuda:%d" % device
     G = 48
-    per = batch // nstreams
-    main_p, imp_p = make_main_params(1003, G), make_imp_params(1003)
+    fc, ic = FusedCodec(G, 64, 128, max_batch=batch, device=device), FusedImpCodec(32, 64, max_batch=batch, device=device)
+    fc.load_layers(make_main_params(1003, G))
+    ic.load_layers(make_imp_params(1003))
     lvl = torch.arange(G, device=dev).view(1, G, 1, 1)
     with torch.no_grad():
         dec.quant.weight.copy_(enc.quant.weight)
-        lanes = []
-        for i in range(nstreams):
-            fc, ic = FusedCodec(G, 64, 128, max_batch=per, device=device), FusedImpCodec(32, 64, max_batch=per, device=device)
-            fc.load_layers(main_p)
-            ic.load_layers(imp_p)
-            lanes.append({"enc": enc if i == 0 else copy.deepcopy(enc), "dec": dec if i == 0 else copy.deepcopy(dec), "fc": fc, "ic": ic,
-                          "st": torch.cuda.Stream(device=dev), "img": torch.rand((per, 3, 512, 1024), device=dev)})
-        torch.cuda.synchronize()
+        img = torch.rand((batch, 3, 512, 1024), device=dev)
+        chunks = [slice(i, i + 8) for i in range(0, batch, 8)]
 
         def run():
-            outs = []
-            for L in lanes:
-                with torch.cuda.stream(L["st"]):
-                    chunks = [slice(i, min(i + 8, per)) for i in range(0, per, 8)]   # the transforms run in chunks of 8 (activation memory)
-                    parts = [L["enc"](L["img"][c]) for c in chunks]
-                    code, mask, lv = (torch.cat([p[k] for p in parts]).contiguous() for k in range(3))
-                    L["fc"].encode_async(code, mask)
-                    L["ic"].encode_async(lv)
-                    L["ic"].decode_async(per)
-                    lv2 = L["ic"].levels_out[:per]
-                    mask2 = (lvl < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
-                    L["fc"].decode_async(mask2, per)
-                    code2 = L["fc"].code_out[:per]
-                    rec = torch.cat([L["dec"](code2[c], mask2[c]) for c in chunks])
-                    outs.append((code, mask, code2, rec))
-            torch.cuda.synchronize()
-            return outs
-        outs = run()
-        exact = all(bool(torch.equal(c2, c * m)) and bool(torch.isfinite(r).all()) for c, m, c2, r in outs)
+            parts = [enc(img[c]) for c in chunks]                           # the transforms run in sub-batches of 8 (activation memory)
+            code, mask, lv = (torch.cat([p[k] for p in parts]).contiguous() for k in range(3))
+            fc.encode_async(code, mask)
+            ic.encode_async(lv)
+            ic.decode_async(batch)
+            lv2 = ic.levels_out[:batch]
+            mask2 = (lvl < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
+            fc.decode_async(mask2, batch)
+            code2 = fc.code_out[:batch]
+            rec = torch.cat([dec(code2[c], mask2[c]) for c in chunks])
+            return code, mask, code2, rec
+        code, mask, code2, rec = run()
+        torch.cuda.synchronize()
+        exact = bool(torch.equal(code2, code * mask)) and bool(torch.isfinite(rec).all())
         t0 = time.time()
         for _ in range(reps):
             run()
+        torch.cuda.synchronize()
         dt = (time.time() - t0) / reps
-    n = per * nstreams
-    return {"kernel": "whole codec: analysis + entropy encode + entropy decode + synthesis", "bound": "mfma", "images_per_launch": n, "streams": nstreams,
-            "ms_per_image": dt / n * 1e3, "achieved": n * 512 * 1024 / dt / 1e6, "unit": "Mpixel/s (%d streams, both directions, transforms included)" % nstreams,
-            "peak": None, "frac": None, "roundtrip_exact": exact, "mean_latent_bytes": float(np.mean([float(L["fc"].nbytes[:per].float().mean().item()) for L in lanes]))}
+    return {"kernel": "whole codec: analysis + entropy encode + entropy decode + synthesis", "bound": "mfma", "images_per_launch": batch,
+            "ms_per_image": dt / batch * 1e3, "achieved": batch * 512 * 1024 / dt / 1e6, "unit": "Mpixel/s (one stream, both directions, transforms included)",
+            "peak": None, "frac": None, "roundtrip_exact": exact, "mean_latent_bytes": float(fc.nbytes[:batch].float().mean().item())}
 
 
 if __name__ == "__main__":
