@@ -34,8 +34,9 @@ struct S3Args {
     const float *x, *w, *bias, *slope, *res;
     float *out;
     int n, cin, cout, hp, wp;                        // x: [n][cin][hp][wp]; cout = output channels of this launch (all blocks)
-    int pad, sphere;                                 // sphere != 0: cells of the `pad`-wide apron are read from the interior by index
-    int ring;                                        // output window = rows [ring, hp - ring) x columns [ring, wp - ring) of the input grid
+    int pad, sphere;                                 // 1: cells of the `pad`-wide apron are read from the interior by the sphere rule; 2: longitude wrap only
+                                                     // (rows as they are: a map whose pole rows hold computed values, the 1-ring output of another launch)
+    int ring, ringw;                                 // output window = rows [ring, hp - ring) x columns [ringw, wp - ringw) of the input grid
     int rw, tall_last;                               // rows per wave of a tile; tall_last != 0: the last tile row runs rw + 1 rows per wave (the window's remainder rows)
     int ohp, owp, ooff;                              // out: [n][cout][ohp][owp], window cell (ph, pw) at (ph - ooff, pw - ooff)
     int tiles_x, tiles_y;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
     float (*xs)[S3_BUF] = (float (*)[S3_BUF])lds;
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mq = wave % NQ, nh = wave / NQ;
-    const int tr0 = a.ring + ty * (NR * a.rw), tc0 = a.ring + tx * S3_T;    // input-grid cell of the tile's first output (a.rw: rows per wave of the ordinary tile rows)
+    const int tr0 = a.ring + ty * (NR * a.rw), tc0 = a.ringw + tx * S3_T;    // input-grid cell of the tile's first output (a.rw: rows per wave of the ordinary tile rows)
     const int blk = blockIdx.y, cblk = NQ * 48;
     const long PLg = (long)a.hp * a.wp;
     // ---- this lane's cells of a chunk's LDS image: LDS float q = (i * 8 + wave) * 64 + lane <-> (channel q / 336, halo row, halo column)
@@ -102,7 +103,8 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
         int ph = tr0 - 1 + r, pw = tc0 - 1 + c;
         ph = ph < 0 ? 0 : (ph > a.hp - 1 ? a.hp - 1 : ph);                  // (only cells of outputs outside the window reach past the map)
         pw = pw < 0 ? 0 : (pw > a.wp - 1 ? a.wp - 1 : pw);
-        if (a.sphere) s3_sphere(ph, pw, a.hp, a.wp, a.pad);
+        if (a.sphere == 1) s3_sphere(ph, pw, a.hp, a.wp, a.pad);
+        else if (a.sphere == 2) { const int W = a.wp - 2 * a.pad; pw = pw < a.pad ? pw + W : (pw >= a.pad + W ? pw - W : pw); }
         voff[i] = (unsigned)(((long)ch * PLg + (long)ph * a.wp + pw) * 4);
     }
     const float *xb = a.x + (long)img * a.cin * PLg;
@@ -191,8 +193,8 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
                 const int ph = tr0 + nh * RW + r;
-                const bool ok = ph < a.hp - a.ring && pw < a.wp - a.ring;
-                const long ri = ((long)img * a.cout + co) * PLg + (long)(ok ? ph : a.ring) * a.wp + (ok ? pw : a.ring);
+                const bool ok = ph < a.hp - a.ring && pw < a.wp - a.ringw;
+                const long ri = ((long)img * a.cout + co) * PLg + (long)(ok ? ph : a.ring) * a.wp + (ok ? pw : a.ringw);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) rv[r][v] = resp[ri + v * PLg];
             }
@@ -200,7 +202,7 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int ph = tr0 + nh * RW + r;
-            if (ph < a.hp - a.ring && pw < a.wp - a.ring) {
+            if (ph < a.hp - a.ring && pw < a.wp - a.ringw) {
                 const long o = ((long)img * a.cout + co) * oPL + (long)(ph - a.ooff) * a.owp + (pw - a.ooff);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -236,16 +238,17 @@ LIC360_API int lic360_sconv3x3_pack(void *stream, const float *weight, float *pa
     return 0;
 }
 LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int out_crop) {
-    ARG_CHECK(x && packed && bias && out && n > 0 && s3_ok(cin, cout) && pad >= 0 && ring >= 1 && hp > 2 * ring && wp > 2 * ring && out_crop >= 0 && out_crop <= ring);
+                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop) {
+    ARG_CHECK(x && packed && bias && out && n > 0 && s3_ok(cin, cout) && pad >= 0 && ring >= 1 && ring_w >= ring && hp > 2 * ring && wp > 2 * ring_w && out_crop >= 0 &&
+              out_crop <= ring && sphere >= 0 && sphere <= 2);
     ARG_CHECK(!sphere || (pad >= 1 && hp >= 4 * pad && wp >= 4 * pad));     // the wrapped / reflected source of an apron cell is an interior cell
     ARG_CHECK((double)S3_CK * hp * wp * 4.0 < 4294967296.0 && ((uintptr_t)bias & 15) == 0 && (!slope || ((uintptr_t)slope & 15) == 0));
     ARG_CHECK(!residual || out_crop == 0);                                  // the residual has the input's geometry
     S3Args a;
     a.x = x; a.w = packed; a.bias = bias; a.slope = slope; a.res = residual; a.out = out;
-    a.n = n; a.cin = cin; a.cout = cout; a.hp = hp; a.wp = wp; a.pad = pad; a.sphere = sphere; a.ring = ring;
+    a.n = n; a.cin = cin; a.cout = cout; a.hp = hp; a.wp = wp; a.pad = pad; a.sphere = sphere; a.ring = ring; a.ringw = ring_w;
     a.ooff = out_crop; a.ohp = hp - 2 * out_crop; a.owp = wp - 2 * out_crop;
-    a.tiles_x = (wp - 2 * ring + S3_T - 1) / S3_T;
+    a.tiles_x = (wp - 2 * ring_w + S3_T - 1) / S3_T;
     const int nq = cout % 192 == 0 ? 4 : 2, nrg = 8 / nq, nr = hp - 2 * ring, full = nr / S3_T, rem = nr - full * S3_T;
     a.rw = S3_T / nrg;
     a.tall_last = rem > 0 && rem <= nrg && full > 0;                        // the remainder fits one more row per wave of the last tile row

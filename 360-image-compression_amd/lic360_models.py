@@ -18,10 +18,14 @@ def _conv(cin, cout, k, stride=1, pad=0):
     return nn.Conv2d(cin, cout, k, stride, pad)
 
 
-FUSED_MIN_WORKGROUPS = 768          # lic360.sconv3x3 is used from three workgroups per CU on (measured against MIOpen: tools/conv3x3_probe.py)
+FUSED_MIN_WORKGROUPS = 256          # lic360.sconv3x3 is used when its workgroups (330 us each) fill whole rounds of the 256 CUs to 80 % or more: 512 per
+                                    # 260x516 map -- one image is two exact rounds -- but not 128 (measured against MIOpen, batches 1..8: tools/conv3x3_probe.py)
 
 
-def _fusable(conv, x, ring):
+FUSED_MIN_FILL = 0.8
+
+
+def _fusable(conv, x, ring, ring_w=None):
     """does this 3x3 stride-1 convolution of a map with x's batch, height and width run on lic360.sconv3x3?  (inference only: the kernel has
     no backward)"""
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
@@ -32,8 +36,10 @@ def _fusable(conv, x, ring):
     if not lic360.sconv3x3_supported(cin, cout):
         return False
     n, _, hp, wp = x.shape
-    tiles = n * ((hp - 2 * ring + 15) // 16) * ((wp - 2 * ring + 15) // 16) * (cout // 192 if cout % 192 == 0 else 1)
-    return tiles >= FUSED_MIN_WORKGROUPS
+    nr, nc = hp - 2 * ring, wp - 2 * (ring if ring_w is None else ring_w)
+    rows = nr // 16 if 0 < nr % 16 <= (2 if cout % 192 == 0 else 4) and nr >= 16 else (nr + 15) // 16      # (a short remainder rides on the last tile row)
+    tiles = n * rows * ((nc + 15) // 16) * (cout // 192 if cout % 192 == 0 else 1)
+    return tiles >= FUSED_MIN_WORKGROUPS and tiles >= FUSED_MIN_FILL * 256 * ((tiles + 255) // 256)
 
 
 def _packed(conv):
@@ -100,13 +106,15 @@ class ResidualBlockV2(nn.Module):
         self.conv2, self.relu2, self.trim2 = _conv(channels, channels, 3, 1, 1), nn.PReLU(channels), SphereTrim(2, device_id)
 
     def forward(self, x):
-        if _fusable(self.conv1, x, 1) and x.is_contiguous():
-            # conv1 over the apron read by index, output on the 1-ring window (the outermost ring is never read); conv2 reads that as it
-            # is, adds x on the interior; the output's apron is x's refreshed apron, as `x + trim2(...)` leaves it in the reference
+        if _fusable(self.conv1, x, 1, 2) and x.is_contiguous():
+            # conv1 over the apron read by index, output on the rows of the 1-ring window (the outermost ring is never read) and on the
+            # interior's columns only: its input is periodic in longitude, so its 1-ring COLUMNS would repeat its interior's last / first
+            # column bit for bit -- conv2 reads them there (longitude wrap), reads the rows as they are, adds x on the interior; the
+            # output's apron is x's refreshed apron, as `x + trim2(...)` leaves it in the reference
             y1 = _scratch(self, "_s3_y1", x.shape, x)
-            lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, y1, pad=2, sphere=True, ring=1)
+            lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, y1, pad=2, sphere=1, ring=1, ring_w=2)
             out = torch.empty_like(x)
-            lic360.sconv3x3(y1, _packed(self.conv2), self.conv2.bias, self.relu2.weight, x, out, pad=2, sphere=False, ring=2)
+            lic360.sconv3x3(y1, _packed(self.conv2), self.conv2.bias, self.relu2.weight, x, out, pad=2, sphere=2, ring=2)
             return lic360.sphere_apron_from(x, out, 2)
         y = self.trim1(self.relu1(self.conv1(self.pad(x))))
         return x + self.trim2(self.relu2(self.conv2(y)))

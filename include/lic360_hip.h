@@ -313,8 +313,10 @@ int lic360_gdn(void *stream, const float *x, const float *gamma, const float *be
 /* ---- f1 3x3 stride-1 convolution on sphere-apron maps with the apron read BY INDEX in the tile loader and bias + PReLU + residual in the
  * epilogue (csrc/conv3x3_kernels.hip): replaces, per layer, nn.Conv2d(c, c', 3, 1, 1 | 0) + the in-place SpherePad in front of it + the
  * nn.PReLU + SphereTrim (+ residual add) behind it in test/model_zoo.py:8-23,45-62,64-94,144-169 (sphere rule: extension/sphere_pad_cuda.cu:48-65).
- * x [n][cin][hp][wp]; with sphere != 0 only the interior (pad cells in from every edge) is read, apron cells come from the interior by the
- * sphere rule; out [n][cout][hp - 2 crop][wp - 2 crop]: the cells of rows [ring, hp - ring) x columns [ring, wp - ring) of the input grid are
+ * x [n][cin][hp][wp]; sphere = 1: only the interior (pad cells in from every edge) is read, apron cells come from the interior by the sphere
+ * rule; sphere = 2: longitude wrap only (columns of the apron come from the interior, rows are read as they are: the input is the 1-ring output
+ * of another launch, whose wrapped columns need not be computed twice); sphere = 0: read as it is.
+ * out [n][cout][hp - 2 crop][wp - 2 crop]: the cells of rows [ring, hp - ring) x columns [ring_w, wp - ring_w) of the input grid are
  * written (out = conv + bias; PReLU if slope; + residual [n][cout][hp][wp] if given), the others are NOT touched (SphereTrim(ring) = leave or
  * zero them: lic360_sphere_trim / lic360_sphere_apron_from).  crop = 1 is the unpadded nn.Conv2d(.., 3, 1) of ResidualBlockUp.conv1.
  * fp32 MFMA, this kernel's own summation order (1e-4 against a library convolution).  cin % 16 == 0, cout in {96} or a multiple of 192;
@@ -323,7 +325,7 @@ int lic360_sconv3x3_supported(int cin, int cout);
 long lic360_sconv3x3_packed_floats(int cin, int cout);
 int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int cin, int cout);
 int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                    int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int crop);
+                    int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int crop);
 /* apron of dst <- sphere-wrapped interior of src (src == dst: lic360_sphere_pad_inplace); [nc][hp][wp] planes      sphere_pad_cuda.cu:48-65 */
 int lic360_sphere_apron_from(void *stream, const float *src, float *dst, int nc, int hp, int wp, int pad);
 

@@ -156,29 +156,37 @@ def test_blocks_match_the_oracle(lic):
             assert np.allclose(got, want, rtol=1e-4, atol=1e-4), "%s: max abs error %g" % (type(blk).__name__, err)
 
 
-@pytest.mark.parametrize("case", [(32, 96, 20, 36, 2, True, 0, True, True), (16, 192, 21, 37, 1, True, 0, True, False), (48, 192, 12, 20, 1, False, 1, True, False),
-                                  (32, 384, 18, 34, 2, False, 0, False, True), (64, 96, 9, 70, 1, True, 0, False, False)],
-                         ids=lambda c: "%dto%d_%dx%d_ring%d" % (c[0], c[1], c[2], c[3], c[4]))
+@pytest.mark.parametrize("case", [(32, 96, 20, 36, 2, 1, 0, True, True, 2), (16, 192, 21, 37, 1, 1, 0, True, False, 1), (48, 192, 12, 20, 1, 0, 1, True, False, 1),
+                                  (32, 384, 18, 34, 2, 0, 0, False, True, 2), (64, 96, 9, 70, 1, 1, 0, False, False, 1), (32, 192, 22, 40, 1, 1, 0, True, False, 2),
+                                  (16, 192, 38, 24, 2, 2, 0, True, True, 2)],
+                         ids=lambda c: "%dto%d_%dx%d_ring%d_%d_sphere%d" % (c[0], c[1], c[2], c[3], c[4], c[9], c[5]))
 def test_sconv3x3_matches_the_oracle_conv(lic, case):
     """lic360_sconv3x3 (csrc/conv3x3_kernels.hip: apron by index, bias + PReLU + residual in the epilogue, window = the trim) against the
     oracle's restatement of what it replaces: in-place sphere pad -> conv2d -> PReLU -> (+ residual) on the window; cells outside the window
-    are not touched.  Odd sizes (ragged tiles), two output-channel blocks, the unpadded form (crop = 1), plain aprons (sphere = 0)."""
+    are not touched.  Odd sizes (ragged tiles), two output-channel blocks, the unpadded form (crop = 1), plain aprons (sphere = 0), the window
+    without the 1-ring columns (ring_w = 2) and the longitude-wrap-only read (sphere = 2) that ResidualBlockV2's second convolution uses, a
+    window of 16 k + 2 rows (the tall last tile row)."""
     import oracle as orc
-    cin, cout, hp, wp, ring, sphere, crop, act, with_res = case
+    cin, cout, hp, wp, ring, sphere, crop, act, with_res, ring_w = case
     rng = np.random.default_rng(cin + 7 * cout + hp)
     x = rng.standard_normal((2, cin, hp, wp)).astype(np.float32)
     w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
     b, sl = rng.standard_normal(cout).astype(np.float32), rng.random(cout).astype(np.float32)
     res = rng.standard_normal((2, cout, hp, wp)).astype(np.float32) if with_res else None
-    xin = orc.sphere_pad_inplace(x.copy(), 2) if sphere else x
+    xin = x
+    if sphere == 1:
+        xin = orc.sphere_pad_inplace(x.copy(), 2)
+    elif sphere == 2:                                                         # columns of the apron from the interior, rows as they are
+        xin = x.copy()
+        xin[..., :2], xin[..., wp - 2:] = x[..., wp - 4:wp - 2], x[..., 2:4]
     want = orc.conv2d(xin, w, b, 1, 1 - crop)
     if act:
         want = orc.prelu(want, sl)
     dev = lambda t: None if t is None else torch.from_numpy(t).cuda()
     out = torch.full((2, cout, hp - 2 * crop, wp - 2 * crop), 7.0, device="cuda:0")
-    lic.sconv3x3(dev(x), lic.sconv3x3_pack(dev(w)), dev(b), dev(sl) if act else None, dev(res), out, pad=2, sphere=sphere, ring=ring, crop=crop)
+    lic.sconv3x3(dev(x), lic.sconv3x3_pack(dev(w)), dev(b), dev(sl) if act else None, dev(res), out, pad=2, sphere=sphere, ring=ring, crop=crop, ring_w=ring_w)
     got = out.cpu().numpy()
-    win = (slice(None), slice(None), slice(ring - crop, hp - crop - ring), slice(ring - crop, wp - crop - ring))
+    win = (slice(None), slice(None), slice(ring - crop, hp - crop - ring), slice(ring_w - crop, wp - crop - ring_w))
     if with_res:
         want = want + res
     assert np.allclose(got[win], want[win], rtol=1e-4, atol=1e-4), float(np.abs(got[win] - want[win]).max())
@@ -193,6 +201,7 @@ def test_fused_blocks_match_the_oracle_at_full_width(lic, monkeypatch):
     import oracle as orc
     import lic360_models as lm
     monkeypatch.setattr(lm, "FUSED_MIN_WORKGROUPS", 0)
+    monkeypatch.setattr(lm, "FUSED_MIN_FILL", 0.0)
     torch.manual_seed(6)
     c = 192
     x = _refresh(torch.randn((1, c, 12, 20), device="cuda:0")).contiguous()

@@ -22,9 +22,11 @@ def timed(fn, reps=10):
 
 
 torch.manual_seed(0)
+# ring 1 = the first convolution of ResidualBlockV2: rows of the 1-ring window, columns of the interior (its 1-ring columns repeat interior columns: ring_w = 2)
 shapes = [(8, 192, 192, 260, 516, 1, 0), (8, 192, 192, 260, 516, 2, 0), (8, 192, 192, 132, 260, 1, 0), (8, 192, 192, 132, 260, 2, 0),
           (8, 96, 96, 132, 260, 2, 0), (8, 192, 768, 68, 132, 1, 1), (8, 192, 192, 36, 68, 2, 0)]
 if os.environ.get("S3_QUICK"): shapes = shapes[2:3] + shapes[6:7]
+if os.environ.get("S3_N"): shapes = [(int(os.environ["S3_N"]),) + sh[1:] for sh in shapes]      # another batch size (default 8)
 for (n, cin, cout, hp, wp, ring, crop) in shapes:
     x = torch.randn(n, cin, hp, wp, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
@@ -45,20 +47,21 @@ for (n, cin, cout, hp, wp, ring, crop) in shapes:
         return y
 
     def ours():
-        return lic360.sconv3x3(x, pk, b, sl, res, out, pad=2, sphere=True, ring=ring, crop=crop)
+        return lic360.sconv3x3(x, pk, b, sl, res, out, pad=2, sphere=True, ring=ring, crop=crop, ring_w=max(ring, 2 - 2 * crop))
 
     want = lib(True)                                                    # (refreshes x's apron in place: the fused kernel ignores it anyway)
     got = ours()
     if crop == 0:
-        win = (slice(None), slice(None), slice(ring, hp - ring), slice(ring, wp - ring))
+        win = (slice(None), slice(None), slice(ring, hp - ring), slice(2, wp - 2))
         err = (got[win] - want[win]).abs().max().item()
     else:                                                               # unpadded conv: out cell (i, j) = input cell (i + 1, j + 1); window in out coords
         win = (slice(None), slice(None), slice(ring - crop, hp - crop - ring), slice(ring - crop, wp - crop - ring))
         err = (got[win] - want[win]).abs().max().item()
     t_conv, t_full, t_ours = timed(lambda: lib(False)), timed(lambda: lib(True)), timed(ours)
     fl_lib = 2.0 * n * cout * cin * 9 * (hp - 2 * crop) * (wp - 2 * crop)
-    fl_win = 2.0 * n * cout * cin * 9 * (hp - 2 * ring) * (wp - 2 * ring)
+    rw_ = max(ring, 2 - 2 * crop)
+    fl_win = 2.0 * n * cout * cin * 9 * (hp - 2 * ring) * (wp - 2 * rw_)
     print("3x3 %d->%d @%dx%d x%d ring %d crop %d: max|diff| %.2e | MIOpen conv alone %.3f ms (%.1f TF), with pad+prelu+trim+add %.3f ms | sconv3x3 %.3f ms "
           "(%.1f TF on its %dx%d window, %.1f TF nominal) | ours / library-with-epilogue = %.2f" % (
-              cin, cout, hp, wp, n, ring, crop, err, t_conv, fl_lib / t_conv / 1e9, t_full, t_ours, fl_win / t_ours / 1e9, hp - 2 * ring, wp - 2 * ring,
+              cin, cout, hp, wp, n, ring, crop, err, t_conv, fl_lib / t_conv / 1e9, t_full, t_ours, fl_win / t_ours / 1e9, hp - 2 * ring, wp - 2 * rw_,
               fl_lib / t_ours / 1e9, t_ours / t_full), flush=True)
