@@ -200,7 +200,16 @@ class ResidualBlockUp(nn.Module):
         self.cut_edge, self.dtow2, self.trim2 = SphereCutEdge(1, d), Dtow(2, True, d), SphereTrim(2, d)
 
     def forward(self, x):
-        b = self.trim1(self.dtow1(self.relu1(self.conv1(self.pad1(x)))))
+        if _fusable(self.conv1, x, 2) and x.is_contiguous():
+            # the unpadded conv1 (output (h+2) x (w+2)) with PReLU in its epilogue, on the INTERIOR's window only: its 1-ring outputs become the
+            # 2-ring of the shuffled map, which trim1 zeroes; x's apron is read by index (no pad1), and the shortcut's apron cells end in the
+            # rings trim2 zeroes
+            n, c, hp, wp = x.shape
+            b = torch.empty((n, self.conv1.out_channels, hp - 2, wp - 2), dtype=torch.float32, device=x.device)
+            lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, b, pad=2, sphere=1, ring=2, crop=1)
+            b = self.trim1(self.dtow1(b))
+        else:
+            b = self.trim1(self.dtow1(self.relu1(self.conv1(self.pad1(x)))))
         if _fusable(self.conv2, b, 2) and b.is_contiguous():
             b2 = _scratch(self, "_s3_b2", b.shape, b)
             b = self.relu2(lic360.sconv3x3(b, _packed(self.conv2), self.conv2.bias, None, None, b2, pad=2, sphere=True, ring=2))

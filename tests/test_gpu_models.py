@@ -211,7 +211,7 @@ def test_fused_blocks_match_the_oracle_at_full_width(lic, monkeypatch):
     monkeypatch.setattr(lic, "sconv3x3", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     with torch.no_grad():
         for cls, fn, ncalls in ((lm.ResidualBlock, orc.blocks.residual, 1), (lm.ResidualBlockV2, orc.blocks.residual_v2, 2),
-                                (lambda ch, d: lm.ResidualBlockDown(ch, ch, d), orc.blocks.residual_down, 1), (lm.ResidualBlockUp, orc.blocks.residual_up, 1)):
+                                (lambda ch, d: lm.ResidualBlockDown(ch, ch, d), orc.blocks.residual_down, 1), (lm.ResidualBlockUp, orc.blocks.residual_up, 2)):
             blk = cls(c, 0).to("cuda:0")
             for prm in blk.parameters():
                 if prm.dim() <= 2:

@@ -24,7 +24,7 @@ def timed(fn, reps=10):
 torch.manual_seed(0)
 # ring 1 = the first convolution of ResidualBlockV2: rows of the 1-ring window, columns of the interior (its 1-ring columns repeat interior columns: ring_w = 2)
 shapes = [(8, 192, 192, 260, 516, 1, 0), (8, 192, 192, 260, 516, 2, 0), (8, 192, 192, 132, 260, 1, 0), (8, 192, 192, 132, 260, 2, 0),
-          (8, 96, 96, 132, 260, 2, 0), (8, 192, 768, 68, 132, 1, 1), (8, 192, 192, 36, 68, 2, 0)]
+          (8, 96, 96, 132, 260, 2, 0), (8, 192, 768, 68, 132, 2, 1), (8, 192, 768, 132, 260, 2, 1), (8, 192, 768, 36, 68, 2, 1), (8, 192, 192, 36, 68, 2, 0)]
 if os.environ.get("S3_QUICK"): shapes = shapes[2:3] + shapes[6:7]
 if os.environ.get("S3_N"): shapes = [(int(os.environ["S3_N"]),) + sh[1:] for sh in shapes]      # another batch size (default 8)
 for (n, cin, cout, hp, wp, ring, crop) in shapes:
