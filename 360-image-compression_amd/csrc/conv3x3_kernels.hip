@@ -23,12 +23,13 @@
 typedef float s3_f4 __attribute__((ext_vector_type(4)));
 
 #define S3_T 16                                      // tile columns (and rows of the main tile shape)
-#define S3_CK 16                                     // input channels per LDS chunk
-#define S3_XC (S3_T + 2)                             // halo tile columns
 #define S3_THREADS 512
-// tile shapes: TR rows x 16 columns.  LDS plane of a channel: (TR + 2) x 18 floats, pitch rounded up to 16 (mod 64) banks
-constexpr int s3_pitch(int tr) { int p = (tr + 2) * S3_XC; while (p % 64 != 16) ++p; return p; }   // TR = 16: 324 -> 336
-constexpr int s3_ndma(int tr) { return (S3_CK * s3_pitch(tr) + 511) / 512; }                      // DMA instructions per wave and chunk (8 waves x 64 lanes)
+// tile shapes: TR rows x 16 columns, kernel size KS (3, or 1: the transforms' 1x1 layers on the same body).  LDS plane of a channel:
+// (TR + KS - 1) x (16 + KS - 1) floats, pitch rounded up to 16 (mod 64) banks; CK input channels per LDS chunk (16 at KS = 3, 32 at KS = 1)
+constexpr int s3_pitch(int tr, int ks) { int p = (tr + ks - 1) * (S3_T + ks - 1); while (p % 64 != 16) ++p; return p; }   // TR = 16, KS = 3: 324 -> 336
+constexpr int s3_ck(int ks) { return ks == 3 ? 16 : 32; }
+constexpr int s3_ndma(int tr, int ks) { return (s3_ck(ks) * s3_pitch(tr, ks) + 511) / 512; }       // DMA instructions per wave and chunk (8 waves x 64 lanes)
+constexpr int s3_na4(int ks) { return (3 * ks + 3) / 4; }                                          // 16-byte A loads per lane and (channel group, kw) pair: 3 ks row-tile operands
 
 struct S3Args {
     const float *x, *w, *bias, *slope, *res;
@@ -61,31 +62,33 @@ __device__ __forceinline__ void s3_sphere(int &ph, int &pw, int hp, int wp, int 
     ph = th + pad; pw = tw + pad;
 }
 
-// weights: [cout block of NQ * 48][cin / 4][kw][mq][j = 0..2][lane] x 4 floats; lane l = 16 k + i, element e = 4 j + t = 3 kh + mt (e < 9):
+// weights: [cout block of NQ * 48][cin / 4][kw < ks][mq][j < na4][lane] x 4 floats; lane l = 16 k + i, element e = 4 j + t = 3 kh + mt (e < 3 ks):
 // W[co = 48 mq + 16 mt + i][ci = 4 cg + k][kh][kw] -- the A operand of the MFMA for (kh, row tile mt)
-__global__ void k_sconv3x3_pack(const float *__restrict__ w, float *__restrict__ packed, int cin, int cout, int nq, long total) {
+__global__ void k_sconv3x3_pack(const float *__restrict__ w, float *__restrict__ packed, int cin, int cout, int nq, int ks, long total) {
+    const int na4 = (3 * ks + 3) / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int t = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
         long r = idx >> 8;
-        const int j = (int)(r % 3); r /= 3;
+        const int j = (int)(r % na4); r /= na4;
         const int mq = (int)(r % nq); r /= nq;
-        const int kw = (int)(r % 3); r /= 3;
+        const int kw = (int)(r % ks); r /= ks;
         const int cg = (int)(r % (cin / 4)), blk = (int)(r / (cin / 4));
         const int e = 4 * j + t, kh = e / 3, mt = e - 3 * kh;
         float v = 0.0f;
-        if (e < 9) {
+        if (e < 3 * ks) {
             const int co = blk * nq * 48 + 48 * mq + 16 * mt + (lane & 15), ci = 4 * cg + (lane >> 4);
-            v = w[(((long)co * cin + ci) * 3 + kh) * 3 + kw];
+            v = w[(((long)co * cin + ci) * ks + kh) * ks + kw];
         }
         packed[idx] = v;
     }
 }
 
-template <int NQ, int RW, int PD>                                           // NQ * 48 output channels per workgroup, RW rows per wave, A operands PD pairs ahead
+template <int NQ, int RW, int PD, int KS>                                   // NQ * 48 output channels per workgroup, RW rows per wave, A operands PD pairs ahead, KS x KS taps
 __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int tx, int img) {
-    static_assert(12 % (PD + 1) == 0, "the operand ring's index must be static across chunks of 12 pairs");
     constexpr int NR = 8 / NQ, TR = NR * RW;                                // row groups per workgroup, tile rows
-    constexpr int S3_PL = s3_pitch(TR), S3_NDMA = s3_ndma(TR), S3_BUF = 8 * S3_NDMA * 64, S3_XR = TR + 2;
+    constexpr int S3_CK = s3_ck(KS), NPAIR = S3_CK / 4 * KS, NA4 = s3_na4(KS), S3_XC = S3_T + KS - 1;
+    constexpr int S3_PL = s3_pitch(TR, KS), S3_NDMA = s3_ndma(TR, KS), S3_BUF = 8 * S3_NDMA * 64, S3_XR = TR + KS - 1;
+    static_assert(NPAIR % (PD + 1) == 0, "the operand ring's index must be static across chunks");
     float (*xs)[S3_BUF] = (float (*)[S3_BUF])lds;
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), mq = wave % NQ, nh = wave / NQ;
@@ -100,7 +103,7 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
         int ch = q / S3_PL, rem = q - ch * S3_PL;
         if (ch >= S3_CK || rem >= S3_XR * S3_XC) { ch = 0; rem = 0; }      // pitch padding and the slack behind the last plane: any valid cell
         const int r = rem / S3_XC, c = rem - r * S3_XC;
-        int ph = tr0 - 1 + r, pw = tc0 - 1 + c;
+        int ph = tr0 - KS / 2 + r, pw = tc0 - KS / 2 + c;
         ph = ph < 0 ? 0 : (ph > a.hp - 1 ? a.hp - 1 : ph);                  // (only cells of outputs outside the window reach past the map)
         pw = pw < 0 ? 0 : (pw > a.wp - 1 ? a.wp - 1 : pw);
         if (a.sphere == 1) s3_sphere(ph, pw, a.hp, a.wp, a.pad);
@@ -115,18 +118,25 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
 #pragma unroll
         for (int i = 0; i < S3_NDMA; ++i) s3_dma(voff[i], sb, lb + (unsigned)(i * 8 * 64 * 4));
     };
-    const int nck = a.cin / S3_CK, niter = nck * 12;
+    const int nck = a.cin / S3_CK, niter = nck * NPAIR;
     // A operands: asm loads + counted waits (hipcc sinks visible loads to just before their first use to save registers, which leaves their
     // L2 latency exposed twice per pair; here the three 16-byte loads of pair it + 1 are issued at the top of pair it and waited for at the
     // top of pair it + 1).  In-order counter: a chunk's 11 DMAs are issued BEHIND the A loads of its first pair, so `vmcnt(11)` at the second
     // pair waits for the operands only and the DMAs have two pairs (~9000 cycles) before a `vmcnt(0)` asks for them.
-    const char *wl = (const char *)((const s3_f4 *)a.w + ((long)blk * (a.cin / 4) * 3 * NQ + mq) * 3 * 64 + lane);   // + it * NQ * 3072 bytes per (cg, kw) pair
+    const char *wl = (const char *)((const s3_f4 *)a.w + ((long)blk * (a.cin / 4) * KS * NQ + mq) * NA4 * 64 + lane);   // + it * NQ * NA4 KB per (cg, kw) pair
     auto load_a = [&](int it, s3_f4 (&A)[3]) __attribute__((always_inline)) {
-        const char *p = wl + (long)it * (NQ * 3072);
-        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
-                     : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]) : "v"(p));
+        const char *p = wl + (long)it * (NQ * NA4 * 1024);
+        if constexpr (NA4 == 3)
+            asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
+                         : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]) : "v"(p));
+        else
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(A[0]) : "v"(p));
     };
-#define S3_WAIT_A(N, A_) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]) : "n"(N))
+#define S3_WAIT_A(N, A_)                                                                                              \
+    do {                                                                                                              \
+        if constexpr (NA4 == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]) : "n"(N)); \
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(A_[0]) : "n"(N));                                              \
+    } while (0)
     s3_f4 acc[3][RW];
 #pragma unroll
     for (int m = 0; m < 3; ++m)
@@ -142,29 +152,29 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
     __syncthreads();
     for (int ck = 0; ck < nck; ++ck) {
         const float *xl = &xs[ck & 1][kq * S3_PL + nh * RW * S3_XC + col];
-        float b[2][RW + 2];
+        float b[2][RW + KS - 1];
 #pragma unroll
-        for (int j = 0; j < RW + 2; ++j) b[0][j] = xl[j * S3_XC];            // pair 0 of the chunk (the later pairs are read one pair ahead)
+        for (int j = 0; j < RW + KS - 1; ++j) b[0][j] = xl[j * S3_XC];       // pair 0 of the chunk (the later pairs are read one pair ahead)
 #pragma unroll
-        for (int p = 0; p < 12; ++p) {                                      // (4-channel group, kw) pairs of the chunk
+        for (int p = 0; p < NPAIR; ++p) {                                   // (4-channel group, kw) pairs of the chunk
             const int cur = p & 1, nxt = cur ^ 1, sa = p % (PD + 1), sn = (p + PD) % (PD + 1);
             // in-order counter: behind set sa's loads came PD - 1 younger sets and -- for the PD pairs that follow a chunk's first -- its DMAs
-            if (p >= 1 && p <= PD) S3_WAIT_A(3 * (PD - 1) + S3_NDMA, A[sa]);  // (registers written by an asm load are only read behind the wait that names them)
-            else S3_WAIT_A(3 * (PD - 1), A[sa]);
-            const int itn = ck * 12 + p + PD;
+            if (p >= 1 && p <= PD) S3_WAIT_A(NA4 * (PD - 1) + S3_NDMA, A[sa]);  // (registers written by an asm load are only read behind the wait that names them)
+            else S3_WAIT_A(NA4 * (PD - 1), A[sa]);
+            const int itn = ck * NPAIR + p + PD;
             load_a(itn < niter ? itn : niter - 1, A[sn]);
             if (p == 0 && ck + 1 < nck) issue_dma(ck + 1);
             if (p == 0 && ck + 1 >= nck) {                                   // keep the counts of the waits at p = 1 .. PD right: harmless loads into the idle buffer
 #pragma unroll
                 for (int i = 0; i < S3_NDMA; ++i) s3_dma(voff[i], s3_uniform(xb), lds0 + (unsigned)(((ck & 1) ^ 1) * S3_BUF + (i * 8 + wave) * 64) * 4u);
             }
-            if (p + 1 < 12) {
-                const int cgn = (p + 1) / 3, kwn = (p + 1) - 3 * cgn;
+            if (p + 1 < NPAIR) {
+                const int cgn = (p + 1) / KS, kwn = (p + 1) - KS * cgn;
 #pragma unroll
-                for (int j = 0; j < RW + 2; ++j) b[nxt][j] = xl[cgn * 4 * S3_PL + j * S3_XC + kwn];
+                for (int j = 0; j < RW + KS - 1; ++j) b[nxt][j] = xl[cgn * 4 * S3_PL + j * S3_XC + kwn];
             }
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -218,31 +228,32 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
 
 // A window of 16 k + 2 rows (every 1-ring window of these maps) would need a seventeenth tile row with 14 dead rows; instead its LAST tile row
 // runs one more row per wave (18 rows at 192 channels, 20 at 96): the workgroup picks its body by its tile row (uniform per workgroup).
-template <int NQ, int RW>
+template <int NQ, int RW, int KS>
 __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
     constexpr int NR = 8 / NQ;
-    __shared__ float lds[2 * 8 * s3_ndma(NR * (RW + 1)) * 64];
+    __shared__ float lds[2 * 8 * s3_ndma(NR * (RW + (KS == 3 ? 1 : 0)), KS) * 64];
     const int tpi = a.tiles_x * a.tiles_y, img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi, ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-    if (a.tall_last && ty == a.tiles_y - 1) s3_body<NQ, RW + 1, 1>(a, lds, ty, tx, img);
-    else s3_body<NQ, RW, 1>(a, lds, ty, tx, img);
+    if constexpr (KS == 3) {
+        if (a.tall_last && ty == a.tiles_y - 1) { s3_body<NQ, RW + 1, 1, 3>(a, lds, ty, tx, img); return; }
+    }
+    s3_body<NQ, RW, 1, KS>(a, lds, ty, tx, img);
 }
 
-static inline bool s3_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout >= 96 && (cout % 192 == 0 || cout == 96); }
-LIC360_API int lic360_sconv3x3_supported(int cin, int cout) { return s3_ok(cin, cout) ? 1 : 0; }
-LIC360_API long lic360_sconv3x3_packed_floats(int cin, int cout) { return s3_ok(cin, cout) ? (long)cout / 48 * (cin / 4) * 3 * 3 * 256 : 0; }
-LIC360_API int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int cin, int cout) {
-    ARG_CHECK(weight && packed && s3_ok(cin, cout));
-    const long total = lic360_sconv3x3_packed_floats(cin, cout);
-    hipLaunchKernelGGL(k_sconv3x3_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, cin, cout, cout % 192 == 0 ? 4 : 2, total);
+static inline bool s3_ok(int cin, int cout, int ks = 3) { return (ks == 3 || ks == 1) && cin >= s3_ck(ks) && cin % s3_ck(ks) == 0 && cout >= 96 && (cout % 192 == 0 || cout == 96); }
+static inline long s3_packed(int cin, int cout, int ks) { return s3_ok(cin, cout, ks) ? (long)cout / 48 * (cin / 4) * ks * s3_na4(ks) * 256 : 0; }
+static int s3_pack(void *stream, const float *weight, float *packed, int cin, int cout, int ks) {
+    ARG_CHECK(weight && packed && s3_ok(cin, cout, ks));
+    const long total = s3_packed(cin, cout, ks);
+    hipLaunchKernelGGL(k_sconv3x3_pack, dim3(lic360_blocks(total, 4)), dim3(256), 0, (hipStream_t)stream, weight, packed, cin, cout, cout % 192 == 0 ? 4 : 2, ks, total);
     LAUNCH_CHECK();
     return 0;
 }
-LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop) {
-    ARG_CHECK(x && packed && bias && out && n > 0 && s3_ok(cin, cout) && pad >= 0 && ring >= 1 && ring_w >= ring && hp > 2 * ring && wp > 2 * ring_w && out_crop >= 0 &&
+static int s3_launch(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
+                     int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop, int ks) {
+    ARG_CHECK(x && packed && bias && out && n > 0 && s3_ok(cin, cout, ks) && pad >= 0 && ring >= ks / 2 && ring_w >= ring && hp > 2 * ring && wp > 2 * ring_w && out_crop >= 0 &&
               out_crop <= ring && sphere >= 0 && sphere <= 2);
     ARG_CHECK(!sphere || (pad >= 1 && hp >= 4 * pad && wp >= 4 * pad));     // the wrapped / reflected source of an apron cell is an interior cell
-    ARG_CHECK((double)S3_CK * hp * wp * 4.0 < 4294967296.0 && ((uintptr_t)bias & 15) == 0 && (!slope || ((uintptr_t)slope & 15) == 0));
+    ARG_CHECK((double)s3_ck(ks) * hp * wp * 4.0 < 4294967296.0 && ((uintptr_t)bias & 15) == 0 && (!slope || ((uintptr_t)slope & 15) == 0));
     ARG_CHECK(!residual || out_crop == 0);                                  // the residual has the input's geometry
     S3Args a;
     a.x = x; a.w = packed; a.bias = bias; a.slope = slope; a.res = residual; a.out = out;
@@ -251,12 +262,30 @@ LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed
     a.tiles_x = (wp - 2 * ring_w + S3_T - 1) / S3_T;
     const int nq = cout % 192 == 0 ? 4 : 2, nrg = 8 / nq, nr = hp - 2 * ring, full = nr / S3_T, rem = nr - full * S3_T;
     a.rw = S3_T / nrg;
-    a.tall_last = rem > 0 && rem <= nrg && full > 0;                        // the remainder fits one more row per wave of the last tile row
+    a.tall_last = ks == 3 && rem > 0 && rem <= nrg && full > 0;             // the remainder fits one more row per wave of the last tile row
     a.tiles_y = a.tall_last ? full : (nr + S3_T - 1) / S3_T;
     const long tiles = (long)n * a.tiles_x * a.tiles_y;
     ARG_CHECK(tiles < (1L << 31));
-    if (nq == 4) hipLaunchKernelGGL((k_sconv3x3<4, 8>), dim3((unsigned)tiles, cout / 192), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_sconv3x3<2, 4>), dim3((unsigned)tiles, 1), dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)tiles, nq == 4 ? cout / 192 : 1);
+    if (ks == 3 && nq == 4) hipLaunchKernelGGL((k_sconv3x3<4, 8, 3>), grid, dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    else if (ks == 3) hipLaunchKernelGGL((k_sconv3x3<2, 4, 3>), grid, dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    else if (nq == 4) hipLaunchKernelGGL((k_sconv3x3<4, 8, 1>), grid, dim3(S3_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_sconv3x3<2, 4, 1>), grid, dim3(S3_THREADS), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return 0;
+}
+LIC360_API int lic360_sconv3x3_supported(int cin, int cout) { return s3_ok(cin, cout, 3) ? 1 : 0; }
+LIC360_API long lic360_sconv3x3_packed_floats(int cin, int cout) { return s3_packed(cin, cout, 3); }
+LIC360_API int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int cin, int cout) { return s3_pack(stream, weight, packed, cin, cout, 3); }
+LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
+                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop) {
+    return s3_launch(stream, x, packed, bias, slope, residual, out, n, cin, cout, hp, wp, pad, sphere, ring, ring_w, out_crop, 3);
+}
+// the transforms' 1x1 layers on the same body (K = input channels only, no halo): bias + PReLU + residual in the epilogue, the window as above
+LIC360_API int lic360_sconv1x1_supported(int cin, int cout) { return s3_ok(cin, cout, 1) ? 1 : 0; }
+LIC360_API long lic360_sconv1x1_packed_floats(int cin, int cout) { return s3_packed(cin, cout, 1); }
+LIC360_API int lic360_sconv1x1_pack(void *stream, const float *weight, float *packed, int cin, int cout) { return s3_pack(stream, weight, packed, cin, cout, 1); }
+LIC360_API int lic360_sconv1x1(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
+                               int n, int cin, int cout, int hp, int wp, int ring, int ring_w) {
+    return s3_launch(stream, x, packed, bias, slope, residual, out, n, cin, cout, hp, wp, 0, 0, ring, ring_w, 0, 1);
 }

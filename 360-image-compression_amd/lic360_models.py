@@ -43,10 +43,11 @@ def _fusable(conv, x, ring, ring_w=None):
 
 
 def _packed(conv):
-    """the conv's weight in lic360.sconv3x3's operand order, repacked when the parameter was written (its version counter) or moved"""
+    """the conv's weight in lic360.sconv3x3's / sconv1x1's operand order, repacked when the parameter was written (its version counter) or moved"""
     key = (conv.weight.data_ptr(), conv.weight._version)
     if getattr(conv, "_s3_key", None) != key:
-        conv._s3_packed, conv._s3_key = lic360.sconv3x3_pack(conv.weight.detach()), key
+        pack = lic360.sconv3x3_pack if conv.kernel_size == (3, 3) else lic360.sconv1x1_pack
+        conv._s3_packed, conv._s3_key = pack(conv.weight.detach()), key
     return conv._s3_packed
 
 
@@ -71,12 +72,23 @@ class ResidualBlock(nn.Module):
         self.trim = SphereTrim(2, device_id)
 
     def forward(self, x):
-        if _fusable(self.conv2, x, 2):
+        if _fusable(self.conv2, x, 2) and x.is_contiguous():
             # conv1 and PReLU are pointwise, so the apron of relu1(conv1(pad(x))) is the sphere wrap of its own interior: conv2 reads it
-            # by index and x needs no refresh; only the interior of conv2's output survives the final trim
-            y = self.relu1(self.conv1(x)).contiguous()
+            # by index and x needs no refresh; only the interior of conv2's output survives the final trim.  The 1x1 layers run on the same
+            # kernel body with their PReLU / residual add in the epilogue (interior window only) when their shapes allow it.
+            n, c, hp, wp = x.shape
+            one = lic360.sconv1x1_supported(c, c // 2) and lic360.sconv1x1_supported(c // 2, c) and self.conv1.bias is not None and self.conv3.bias is not None
+            if one:
+                y = _scratch(self, "_s3_y", (n, c // 2, hp, wp), x)
+                lic360.sconv1x1(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, y, ring=2)
+            else:
+                y = self.relu1(self.conv1(x)).contiguous()
             y2 = _scratch(self, "_s3_y2", y.shape, y)
             lic360.sconv3x3(y, _packed(self.conv2), self.conv2.bias, self.relu2.weight, None, y2, pad=2, sphere=True, ring=2)
+            if one:
+                out = torch.empty_like(x)
+                lic360.sconv1x1(y2, _packed(self.conv3), self.conv3.bias, None, x, out, ring=2)
+                return self.trim(out)
             return self.trim(x + self.conv3(y2))
         y = self.pad(x)
         y = self.relu2(self.conv2(self.relu1(self.conv1(y))))

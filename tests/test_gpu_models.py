@@ -195,6 +195,34 @@ def test_sconv3x3_matches_the_oracle_conv(lic, case):
     assert np.all(got[frame] == 7.0)
 
 
+@pytest.mark.parametrize("case", [(64, 96, 20, 36, 2, 2, True, False), (96, 192, 21, 37, 2, 2, False, True), (32, 384, 12, 20, 1, 3, True, True)],
+                         ids=lambda c: "%dto%d_%dx%d" % (c[0], c[1], c[2], c[3]))
+def test_sconv1x1_matches_the_oracle_conv(lic, case):
+    """lic360_sconv1x1 (the transforms' 1x1 layers on the 3x3 kernel's body) against the oracle's conv2d -> PReLU -> + residual on the window;
+    cells outside the window are not touched"""
+    import oracle as orc
+    cin, cout, hp, wp, ring, ring_w, act, with_res = case
+    rng = np.random.default_rng(3 * cin + cout + wp)
+    x = rng.standard_normal((2, cin, hp, wp)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 1, 1)) * 0.1).astype(np.float32)
+    b, sl = rng.standard_normal(cout).astype(np.float32), rng.random(cout).astype(np.float32)
+    res = rng.standard_normal((2, cout, hp, wp)).astype(np.float32) if with_res else None
+    want = orc.conv2d(x, w, b, 1, 0)
+    if act:
+        want = orc.prelu(want, sl)
+    if with_res:
+        want = want + res
+    dev = lambda t: None if t is None else torch.from_numpy(t).cuda()
+    out = torch.full((2, cout, hp, wp), 7.0, device="cuda:0")
+    lic.sconv1x1(dev(x), lic.sconv1x1_pack(dev(w)), dev(b), dev(sl) if act else None, dev(res), out, ring=ring, ring_w=ring_w)
+    got = out.cpu().numpy()
+    win = (slice(None), slice(None), slice(ring, hp - ring), slice(ring_w, wp - ring_w))
+    assert np.allclose(got[win], want[win], rtol=1e-4, atol=1e-4), float(np.abs(got[win] - want[win]).max())
+    frame = np.ones(got.shape, bool)
+    frame[win] = False
+    assert np.all(got[frame] == 7.0)
+
+
 def test_fused_blocks_match_the_oracle_at_full_width(lic, monkeypatch):
     """the transform blocks at the reference's width (192 channels), where their 3x3 stride-1 convolutions run on lic360.sconv3x3 (forced
     here for a small map), against the oracle's blocks: the whole output, aprons included"""

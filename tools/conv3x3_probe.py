@@ -65,3 +65,21 @@ for (n, cin, cout, hp, wp, ring, crop) in shapes:
           "(%.1f TF on its %dx%d window, %.1f TF nominal) | ours / library-with-epilogue = %.2f" % (
               cin, cout, hp, wp, n, ring, crop, err, t_conv, fl_lib / t_conv / 1e9, t_full, t_ours, fl_win / t_ours / 1e9, hp - 2 * ring, wp - 2 * rw_,
               fl_lib / t_ours / 1e9, t_ours / t_full), flush=True)
+
+# ---- the 1x1 layers of ResidualBlock on the same kernel body, against the library GEMM (+ the elementwise launch each one absorbs)
+for (n, cin, cout, hp, wp, what) in [(8, 192, 96, 132, 260, "prelu"), (8, 96, 192, 132, 260, "add"), (8, 192, 192, 132, 260, "prelu")]:
+    if os.environ.get("S3_N"): n = int(os.environ["S3_N"])
+    x = torch.randn(n, cin, hp, wp, device=dev)
+    w = torch.randn(cout, cin, 1, 1, device=dev) * 0.05
+    b, sl = torch.randn(cout, device=dev), torch.rand(cout, device=dev) * 0.5
+    res = torch.randn(n, cout, hp, wp, device=dev)
+    pk = lic360.sconv1x1_pack(w)
+    out = torch.zeros(n, cout, hp, wp, device=dev)
+    lib = (lambda: F.prelu(F.conv2d(x, w, b), sl)) if what == "prelu" else (lambda: F.conv2d(x, w, b) + res)
+    ours = (lambda: lic360.sconv1x1(x, pk, b, sl, None, out, ring=2)) if what == "prelu" else (lambda: lic360.sconv1x1(x, pk, b, None, res, out, ring=2))
+    win = (slice(None), slice(None), slice(2, hp - 2), slice(2, wp - 2))
+    err = (ours()[win] - lib()[win]).abs().max().item()
+    t_conv, t_lib, t_ours = timed(lambda: F.conv2d(x, w, b)), timed(lib), timed(ours)
+    fl = 2.0 * n * cout * cin * (hp - 4) * (wp - 4)
+    print("1x1 %d->%d @%dx%d x%d + %s: max|diff| %.2e | library conv alone %.3f ms, with the %s %.3f ms | sconv1x1 %.3f ms (%.1f TF on its window) | ours / library = %.2f" % (
+        cin, cout, hp, wp, n, what, err, t_conv, what, t_lib, t_ours, fl / t_ours / 1e9, t_ours / t_lib), flush=True)
