@@ -95,14 +95,22 @@ def whole_codec(enc, dec, device, batch=48, reps=2):
         img = torch.rand((batch, 3, 512, 1024), device=dev)
         chunks = [slice(i, i + 8) for i in range(0, batch, 8)]
 
+        side = torch.cuda.Stream(device=dev)                                # the importance-map stream of the batch (as in bench.py: a stream of its own)
+
         def run():
+            main = torch.cuda.current_stream()
             parts = [enc(img[c]) for c in chunks]                           # the transforms run in sub-batches of 8 (activation memory)
             code, mask, lv = (torch.cat([p[k] for p in parts]).contiguous() for k in range(3))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):                                   # the map's encode + decode (38 ms of small launches) under the latent's encode (136 ms)
+                ic.encode_async(lv)
+                ic.decode_async(batch)
+                lv2 = ic.levels_out[:batch]
+                mask2 = (lvl < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
+            lv.record_stream(side)
+            mask2.record_stream(main)
             fc.encode_async(code, mask)
-            ic.encode_async(lv)
-            ic.decode_async(batch)
-            lv2 = ic.levels_out[:batch]
-            mask2 = (lvl < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
+            main.wait_stream(side)                                          # the latent decode needs the mask the decoded map gives
             fc.decode_async(mask2, batch)
             code2 = fc.code_out[:batch]
             rec = torch.cat([dec(code2[c], mask2[c]) for c in chunks])
@@ -116,9 +124,73 @@ def whole_codec(enc, dec, device, batch=48, reps=2):
         torch.cuda.synchronize()
         dt = (time.time() - t0) / reps
     return {"kernel": "whole codec: analysis + entropy encode + entropy decode + synthesis", "bound": "mfma", "images_per_launch": batch,
-            "ms_per_image": dt / batch * 1e3, "achieved": batch * 512 * 1024 / dt / 1e6, "unit": "Mpixel/s (one stream, both directions, transforms included)",
+            "ms_per_image": dt / batch * 1e3, "achieved": batch * 512 * 1024 / dt / 1e6, "unit": "Mpixel/s (one stream + the importance-map codec on a side stream, both directions, transforms included)",
             "peak": None, "frac": None, "roundtrip_exact": exact, "mean_latent_bytes": float(fc.nbytes[:batch].float().mean().item())}
 
 
+def whole_codec_streams(enc, dec, device, batch=48, reps=2, nstreams=2):
+    """image -> analysis -> both entropy encoders -> bitstreams (in HBM) -> both entropy decoders -> synthesis -> image, seeded weights: the
+    end-to-end rate of the codec on one GPU.  The batch runs as `nstreams` independent sub-batches on HIP streams of their own (as bench.py runs
+    the entropy path): one sub-batch's launch-bound decode planes and serial coder chains fill under another's transforms.  Every stream has its
+    own copy of the networks (the fused blocks keep per-module work buffers) and its own codecs."""
+    import copy
+    import time
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_main_params, make_imp_params
+    from lic360_fused import FusedCodec, FusedImpCodec
+    dev = "cuda:%d" % device
+    G = 48
+    per = batch // nstreams
+    main_p, imp_p = make_main_params(1003, G), make_imp_params(1003)
+    lvl = torch.arange(G, device=dev).view(1, G, 1, 1)
+    with torch.no_grad():
+        dec.quant.weight.copy_(enc.quant.weight)
+        lanes = []
+        for i in range(nstreams):
+            fc, ic = FusedCodec(G, 64, 128, max_batch=per, device=device), FusedImpCodec(32, 64, max_batch=per, device=device)
+            fc.load_layers(main_p)
+            ic.load_layers(imp_p)
+            lanes.append({"enc": enc if i == 0 else copy.deepcopy(enc), "dec": dec if i == 0 else copy.deepcopy(dec), "fc": fc, "ic": ic,
+                          "st": torch.cuda.Stream(device=dev), "img": torch.rand((per, 3, 512, 1024), device=dev)})
+        torch.cuda.synchronize()
+
+        def run():
+            outs = []
+            for L in lanes:
+                with torch.cuda.stream(L["st"]):
+                    chunks = [slice(i, min(i + 8, per)) for i in range(0, per, 8)]   # the transforms run in chunks of 8 (activation memory)
+                    parts = [L["enc"](L["img"][c]) for c in chunks]
+                    code, mask, lv = (torch.cat([p[k] for p in parts]).contiguous() for k in range(3))
+                    L["fc"].encode_async(code, mask)
+                    L["ic"].encode_async(lv)
+                    L["ic"].decode_async(per)
+                    lv2 = L["ic"].levels_out[:per]
+                    mask2 = (lvl < lv2.repeat_interleave(2, 2).repeat_interleave(2, 3)).float()
+                    L["fc"].decode_async(mask2, per)
+                    code2 = L["fc"].code_out[:per]
+                    rec = torch.cat([L["dec"](code2[c], mask2[c]) for c in chunks])
+                    outs.append((code, mask, code2, rec))
+            torch.cuda.synchronize()
+            return outs
+        outs = run()
+        exact = all(bool(torch.equal(c2, c * m)) and bool(torch.isfinite(r).all()) for c, m, c2, r in outs)
+        t0 = time.time()
+        for _ in range(reps):
+            run()
+        dt = (time.time() - t0) / reps
+    n = per * nstreams
+    return {"kernel": "whole codec: analysis + entropy encode + entropy decode + synthesis", "bound": "mfma", "images_per_launch": n, "streams": nstreams,
+            "ms_per_image": dt / n * 1e3, "achieved": n * 512 * 1024 / dt / 1e6, "unit": "Mpixel/s (%d streams, both directions, transforms included)" % nstreams,
+            "peak": None, "frac": None, "roundtrip_exact": exact, "mean_latent_bytes": float(np.mean([float(L["fc"].nbytes[:per].float().mean().item()) for L in lanes]))}
+
+
 if __name__ == "__main__":
-    print(json.dumps({"rows": measure()}, indent=1))
+    if len(sys.argv) > 1 and sys.argv[1] == "streams":                      # the whole codec as N sub-batches on N streams (experiment: N = 2, 3)
+        import lic360_models as lm
+        torch.manual_seed(0)
+        e, d = lm.CMP_Encoder(gpu_id=0).to("cuda:0").eval(), lm.CMP_Decoder(gpu_id=0).to("cuda:0").eval()
+        for ns in (int(v) for v in sys.argv[2:]):
+            print(json.dumps(whole_codec_streams(e, d, 0, nstreams=ns)))
+    else:
+        print(json.dumps({"rows": measure()}, indent=1))
