@@ -236,7 +236,7 @@ __global__ __launch_bounds__(S3_THREADS) void k_sconv3x3(S3Args a) {
     if constexpr (KS == 3) {
         if (a.tall_last && ty == a.tiles_y - 1) { s3_body<NQ, RW + 1, 1, 3>(a, lds, ty, tx, img); return; }
     }
-    s3_body<NQ, RW, 1, KS>(a, lds, ty, tx, img);
+    s3_body<NQ, RW, KS == 3 ? 1 : 3, KS>(a, lds, ty, tx, img);            // a 1x1 pair is 24 MFMAs (768 cycles): its A operand is fetched three pairs ahead
 }
 
 static inline bool s3_ok(int cin, int cout, int ks = 3) { return (ks == 3 || ks == 1) && cin >= s3_ck(ks) && cin % s3_ck(ks) == 0 && cout >= 96 && (cout % 192 == 0 || cout == 96); }
