@@ -70,15 +70,17 @@ def measure(batch=8, device=0, reps=3):
                          "unit": "TFLOP/s", "frac": fl / t_o / 1e12 / F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": fl,
                          "miopen_conv_alone_ms": t_c * 1e3, "miopen_conv_with_pad_prelu_trim_add_ms": t_l * 1e3,
                          "speedup_vs_miopen_conv_alone": t_c / t_o, "speedup_vs_library_form": t_l / t_o})
-    rows.append(whole_codec(enc, dec, device))
+    one = whole_codec(enc, dec, device)                                     # 48 images, one stream (+ the importance codec on a side stream)
+    row = whole_codec_streams(enc, dec, device, batch=144, nstreams=3)      # the bench's own batch structure: 144 images = 3 sub-batches of 48 on 3 streams
+    row["one_stream_48_images_mpixel_s"], row["one_stream_48_images_ms_per_image"] = one["achieved"], one["ms_per_image"]
+    row["roundtrip_exact"] = bool(row["roundtrip_exact"] and one["roundtrip_exact"])
+    rows.append(row)
     return rows
 
 
 def whole_codec(enc, dec, device, batch=48, reps=2):
     """image -> analysis -> both entropy encoders -> bitstreams (in HBM) -> both entropy decoders -> synthesis -> image, one stream, seeded
-    weights: the end-to-end rate of the codec on one GPU.  (Round 5 measured the same 48 images as three sub-batches of 16 on three streams with
-    their own copies of the networks: 19.7 Mpixel/s against 23.7 -- sixteen images per entropy-coder batch lose the decode kernels' sample packing
-    and the transforms gain nothing from running beside each other.)"""
+    weights: the end-to-end rate of the codec on one GPU, one batch of 48 on one stream (see whole_codec_streams for the bench's own structure)."""
     import time
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -132,7 +134,8 @@ def whole_codec_streams(enc, dec, device, batch=48, reps=2, nstreams=2):
     """image -> analysis -> both entropy encoders -> bitstreams (in HBM) -> both entropy decoders -> synthesis -> image, seeded weights: the
     end-to-end rate of the codec on one GPU.  The batch runs as `nstreams` independent sub-batches on HIP streams of their own (as bench.py runs
     the entropy path): one sub-batch's launch-bound decode planes and serial coder chains fill under another's transforms.  Every stream has its
-    own copy of the networks (the fused blocks keep per-module work buffers) and its own codecs."""
+    own copy of the networks (the fused blocks keep per-module work buffers) and its own codecs.  Measured (round 5): 48 images per stream on
+    1 / 2 / 3 streams 24.5 / 25.4 / 25.7 Mpixel/s; 48 images SPLIT over 2 / 3 streams 22.8 / 20.0 (the coder batches lose their sample packing)."""
     import copy
     import time
     import numpy as np
@@ -190,7 +193,8 @@ if __name__ == "__main__":
         import lic360_models as lm
         torch.manual_seed(0)
         e, d = lm.CMP_Encoder(gpu_id=0).to("cuda:0").eval(), lm.CMP_Decoder(gpu_id=0).to("cuda:0").eval()
+        per = int(os.environ.get("WC_PER", 0))                              # images per stream (default: 48 in all, split over the streams)
         for ns in (int(v) for v in sys.argv[2:]):
-            print(json.dumps(whole_codec_streams(e, d, 0, nstreams=ns)))
+            print(json.dumps(whole_codec_streams(e, d, 0, batch=per * ns if per else 48, nstreams=ns)))
     else:
         print(json.dumps({"rows": measure()}, indent=1))
