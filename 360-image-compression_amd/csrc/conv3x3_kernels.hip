@@ -40,6 +40,8 @@ struct S3Args {
     int ring, ringw;                                 // output window = rows [ring, hp - ring) x columns [ringw, wp - ringw) of the input grid
     int rw, tall_last;                               // rows per wave of a tile; tall_last != 0: the last tile row runs rw + 1 rows per wave (the window's remainder rows)
     int ohp, owp, ooff;                              // out: [n][cout][ohp][owp], window cell (ph, pw) at (ph - ooff, pw - ooff)
+    int shuffle;                                     // != 0: out is the x2 pixel shuffle of that (Dtow(2, d2w), dtow_cuda.cu:38-75): [n][cout / 4][2 ohp][2 owp], channel 4 p + v of
+                                                     // cell (y, x) at channel p, cell (2 y + v / 2, 2 x + v % 2) -- a lane's four accumulator registers are one 2 x 2 block
     int tiles_x, tiles_y;
 };
 
@@ -213,13 +215,22 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
         for (int r = 0; r < RW; ++r) {
             const int ph = tr0 + nh * RW + r;
             if (ph < a.hp - a.ring && pw < a.wp - a.ringw) {
-                const long o = ((long)img * a.cout + co) * oPL + (long)(ph - a.ooff) * a.owp + (pw - a.ooff);
+                float y[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    float y = acc[m][r][v] + bs[v];
-                    if (a.slope) y = y > 0.f ? y : y * sl[v];
-                    if (resp) y = y + rv[r][v];
-                    outp[o + v * oPL] = y;
+                    y[v] = acc[m][r][v] + bs[v];
+                    if (a.slope) y[v] = y[v] > 0.f ? y[v] : y[v] * sl[v];
+                    if (resp) y[v] = y[v] + rv[r][v];
+                }
+                if (a.shuffle) {                                           // two 8-byte stores per lane: 16 lanes write 128 contiguous bytes of each of two rows
+                    typedef float s3_f2 __attribute__((ext_vector_type(2)));
+                    const long o = (((long)img * (a.cout >> 2) + (co >> 2)) * (2 * a.ohp) + 2 * (ph - a.ooff)) * (2 * a.owp) + 2 * (pw - a.ooff);
+                    *(s3_f2 *)(outp + o) = (s3_f2){y[0], y[1]};
+                    *(s3_f2 *)(outp + o + 2 * a.owp) = (s3_f2){y[2], y[3]};
+                } else {
+                    const long o = ((long)img * a.cout + co) * oPL + (long)(ph - a.ooff) * a.owp + (pw - a.ooff);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) outp[o + v * oPL] = y[v];
                 }
             }
         }
@@ -249,16 +260,17 @@ static int s3_pack(void *stream, const float *weight, float *packed, int cin, in
     return 0;
 }
 static int s3_launch(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                     int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop, int ks) {
+                     int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop, int ks, int shuffle = 0) {
     ARG_CHECK(x && packed && bias && out && n > 0 && s3_ok(cin, cout, ks) && pad >= 0 && ring >= ks / 2 && ring_w >= ring && hp > 2 * ring && wp > 2 * ring_w && out_crop >= 0 &&
               out_crop <= ring && sphere >= 0 && sphere <= 2);
     ARG_CHECK(!sphere || (pad >= 1 && hp >= 4 * pad && wp >= 4 * pad));     // the wrapped / reflected source of an apron cell is an interior cell
     ARG_CHECK((double)s3_ck(ks) * hp * wp * 4.0 < 4294967296.0 && ((uintptr_t)bias & 15) == 0 && (!slope || ((uintptr_t)slope & 15) == 0));
     ARG_CHECK(!residual || out_crop == 0);                                  // the residual has the input's geometry
+    ARG_CHECK(!shuffle || (!residual && ((uintptr_t)out & 7) == 0));        // the shuffled store writes aligned pairs
     S3Args a;
     a.x = x; a.w = packed; a.bias = bias; a.slope = slope; a.res = residual; a.out = out;
     a.n = n; a.cin = cin; a.cout = cout; a.hp = hp; a.wp = wp; a.pad = pad; a.sphere = sphere; a.ring = ring; a.ringw = ring_w;
-    a.ooff = out_crop; a.ohp = hp - 2 * out_crop; a.owp = wp - 2 * out_crop;
+    a.ooff = out_crop; a.ohp = hp - 2 * out_crop; a.owp = wp - 2 * out_crop; a.shuffle = shuffle;
     a.tiles_x = (wp - 2 * ring_w + S3_T - 1) / S3_T;
     const int nq = cout % 192 == 0 ? 4 : 2, nrg = 8 / nq, nr = hp - 2 * ring, full = nr / S3_T, rem = nr - full * S3_T;
     a.rw = S3_T / nrg;
@@ -278,8 +290,8 @@ LIC360_API int lic360_sconv3x3_supported(int cin, int cout) { return s3_ok(cin, 
 LIC360_API long lic360_sconv3x3_packed_floats(int cin, int cout) { return s3_packed(cin, cout, 3); }
 LIC360_API int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int cin, int cout) { return s3_pack(stream, weight, packed, cin, cout, 3); }
 LIC360_API int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop) {
-    return s3_launch(stream, x, packed, bias, slope, residual, out, n, cin, cout, hp, wp, pad, sphere, ring, ring_w, out_crop, 3);
+                               int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int out_crop, int shuffle) {
+    return s3_launch(stream, x, packed, bias, slope, residual, out, n, cin, cout, hp, wp, pad, sphere, ring, ring_w, out_crop, 3, shuffle);
 }
 // the transforms' 1x1 layers on the same body (K = input channels only, no halo): bias + PReLU + residual in the epilogue, the window as above
 LIC360_API int lic360_sconv1x1_supported(int cin, int cout) { return s3_ok(cin, cout, 1) ? 1 : 0; }

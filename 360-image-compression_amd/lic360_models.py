@@ -216,10 +216,12 @@ class ResidualBlockUp(nn.Module):
             # the unpadded conv1 (output (h+2) x (w+2)) with PReLU in its epilogue, on the INTERIOR's window only: its 1-ring outputs become the
             # 2-ring of the shuffled map, which trim1 zeroes; x's apron is read by index (no pad1), and the shortcut's apron cells end in the
             # rings trim2 zeroes
+            # ... and the pixel shuffle is the kernel's store pattern (a lane's four accumulator registers are one 2 x 2 block of the shuffled
+            # map): conv1 -> PReLU -> Dtow -> trim1 in one launch.  The window lands exactly on the shuffled map's interior; its apron is
+            # never read (conv2 reads aprons by index, or pad2 refreshes it), so trim1 has nothing to do.
             n, c, hp, wp = x.shape
-            b = torch.empty((n, self.conv1.out_channels, hp - 2, wp - 2), dtype=torch.float32, device=x.device)
-            lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, b, pad=2, sphere=1, ring=2, crop=1)
-            b = self.trim1(self.dtow1(b))
+            b = _scratch(self, "_s3_b", (n, self.conv1.out_channels // 4, 2 * (hp - 2), 2 * (wp - 2)), x)
+            lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, b, pad=2, sphere=1, ring=2, crop=1, shuffle=True)
         else:
             b = self.trim1(self.dtow1(self.relu1(self.conv1(self.pad1(x)))))
         if _fusable(self.conv2, b, 2) and b.is_contiguous():

@@ -318,14 +318,16 @@ int lic360_gdn(void *stream, const float *x, const float *gamma, const float *be
  * of another launch, whose wrapped columns need not be computed twice); sphere = 0: read as it is.
  * out [n][cout][hp - 2 crop][wp - 2 crop]: the cells of rows [ring, hp - ring) x columns [ring_w, wp - ring_w) of the input grid are
  * written (out = conv + bias; PReLU if slope; + residual [n][cout][hp][wp] if given), the others are NOT touched (SphereTrim(ring) = leave or
- * zero them: lic360_sphere_trim / lic360_sphere_apron_from).  crop = 1 is the unpadded nn.Conv2d(.., 3, 1) of ResidualBlockUp.conv1.
+ * zero them: lic360_sphere_trim / lic360_sphere_apron_from).  crop = 1 is the unpadded nn.Conv2d(.., 3, 1) of ResidualBlockUp.conv1;
+ * shuffle != 0 stores through Dtow(2, d2w) (extension/dtow_cuda.cu:38-75): out [n][cout / 4][2 (hp - 2 crop)][2 (wp - 2 crop)], channel 4 p + v of a
+ * cell (y, x) at channel p, cell (2 y + v / 2, 2 x + v % 2) -- the conv -> PReLU -> Dtow chain of test/model_zoo.py:160-162 in one launch.
  * fp32 MFMA, this kernel's own summation order (1e-4 against a library convolution).  cin % 16 == 0, cout in {96} or a multiple of 192;
  * packed = lic360_sconv3x3_pack of the [cout][cin][3][3] weight; bias / slope 16-byte aligned. */
 int lic360_sconv3x3_supported(int cin, int cout);
 long lic360_sconv3x3_packed_floats(int cin, int cout);
 int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int cin, int cout);
 int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                    int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int crop);
+                    int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int crop, int shuffle);
 /* the transforms' 1x1 layers on the same kernel body (K = input channels only): replaces nn.Conv2d(c, c', 1) + nn.PReLU (+ residual add) of
  * test/model_zoo.py:8-23 (ResidualBlock.conv1 / conv3).  x / residual / out [n][.][hp][wp]; the cells of rows [ring, hp - ring) x columns
  * [ring_w, wp - ring_w) are written, the others not touched; cin % 32 == 0, cout = 96 or a multiple of 192 */

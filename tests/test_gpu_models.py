@@ -195,6 +195,28 @@ def test_sconv3x3_matches_the_oracle_conv(lic, case):
     assert np.all(got[frame] == 7.0)
 
 
+def test_sconv3x3_with_the_pixel_shuffle_as_its_store_pattern(lic):
+    """the unpadded 3x3 conv -> PReLU -> Dtow(2) chain of ResidualBlockUp (test/model_zoo.py:160-162) in one launch: the shuffled window equals the
+    oracle's sphere pad -> conv2d -> PReLU -> dtow; cells of the shuffled map outside the window are not touched"""
+    import oracle as orc
+    cin, cout, hp, wp = 32, 192, 14, 22
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((2, cin, hp, wp)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3)) * 0.1).astype(np.float32)
+    b, sl = rng.standard_normal(cout).astype(np.float32), rng.random(cout).astype(np.float32)
+    want = orc.dtow(orc.prelu(orc.conv2d(orc.sphere_pad_inplace(x.copy(), 2), w, b, 1, 0), sl), 2, True)       # [2, 48, 2 (hp - 2), 2 (wp - 2)]
+    dev = lambda t: torch.from_numpy(t).cuda()
+    out = torch.full((2, cout // 4, 2 * (hp - 2), 2 * (wp - 2)), 7.0, device="cuda:0")
+    lic.sconv3x3(dev(x), lic.sconv3x3_pack(dev(w)), dev(b), dev(sl), None, out, pad=2, sphere=1, ring=2, crop=1, shuffle=True)
+    got = out.cpu().numpy()
+    assert got.shape == want.shape
+    win = (slice(None), slice(None), slice(2, 2 * (hp - 2) - 2), slice(2, 2 * (wp - 2) - 2))      # the shuffled map's interior
+    assert np.allclose(got[win], want[win], rtol=1e-4, atol=1e-4), float(np.abs(got[win] - want[win]).max())
+    frame = np.ones(got.shape, bool)
+    frame[win] = False
+    assert np.all(got[frame] == 7.0)
+
+
 @pytest.mark.parametrize("case", [(64, 96, 20, 36, 2, 2, True, False), (96, 192, 21, 37, 2, 2, False, True), (32, 384, 12, 20, 1, 3, True, True)],
                          ids=lambda c: "%dto%d_%dx%d" % (c[0], c[1], c[2], c[3]))
 def test_sconv1x1_matches_the_oracle_conv(lic, case):
