@@ -206,9 +206,17 @@ __device__ __forceinline__ void s3_body(const S3Args &a, float *lds, int ty, int
             for (int r = 0; r < RW; ++r) {
                 const int ph = tr0 + nh * RW + r;
                 const bool ok = ph < a.hp - a.ring && pw < a.wp - a.ringw;
-                const long ri = ((long)img * a.cout + co) * PLg + (long)(ok ? ph : a.ring) * a.wp + (ok ? pw : a.ringw);
+                const int rh = ok ? ph : a.ring, rw_ = ok ? pw : a.ringw;
+                if (a.shuffle) {                                           // the residual has the OUTPUT's (shuffled) geometry
+                    typedef float s3_f2 __attribute__((ext_vector_type(2)));
+                    const long ri = (((long)img * (a.cout >> 2) + (co >> 2)) * (2 * a.ohp) + 2 * (rh - a.ooff)) * (2 * a.owp) + 2 * (rw_ - a.ooff);
+                    const s3_f2 lo = *(const s3_f2 *)(resp + ri), hi = *(const s3_f2 *)(resp + ri + 2 * a.owp);
+                    rv[r] = (s3_f4){lo[0], lo[1], hi[0], hi[1]};
+                } else {
+                    const long ri = ((long)img * a.cout + co) * PLg + (long)rh * a.wp + rw_;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) rv[r][v] = resp[ri + v * PLg];
+                    for (int v = 0; v < 4; ++v) rv[r][v] = resp[ri + v * PLg];
+                }
             }
         }
 #pragma unroll
@@ -265,8 +273,8 @@ static int s3_launch(void *stream, const float *x, const float *packed, const fl
               out_crop <= ring && sphere >= 0 && sphere <= 2);
     ARG_CHECK(!sphere || (pad >= 1 && hp >= 4 * pad && wp >= 4 * pad));     // the wrapped / reflected source of an apron cell is an interior cell
     ARG_CHECK((double)s3_ck(ks) * hp * wp * 4.0 < 4294967296.0 && ((uintptr_t)bias & 15) == 0 && (!slope || ((uintptr_t)slope & 15) == 0));
-    ARG_CHECK(!residual || out_crop == 0);                                  // the residual has the input's geometry
-    ARG_CHECK(!shuffle || (!residual && ((uintptr_t)out & 7) == 0));        // the shuffled store writes aligned pairs
+    ARG_CHECK(!residual || out_crop == 0 || shuffle);                       // the residual has the input's geometry -- or, shuffled, the output's
+    ARG_CHECK(!shuffle || (((uintptr_t)out & 7) == 0 && ((uintptr_t)residual & 7) == 0));   // the shuffled store / residual load move aligned pairs
     S3Args a;
     a.x = x; a.w = packed; a.bias = bias; a.slope = slope; a.res = residual; a.out = out;
     a.n = n; a.cin = cin; a.cout = cout; a.hp = hp; a.wp = wp; a.pad = pad; a.sphere = sphere; a.ring = ring; a.ringw = ring_w;
@@ -298,6 +306,6 @@ LIC360_API int lic360_sconv1x1_supported(int cin, int cout) { return s3_ok(cin, 
 LIC360_API long lic360_sconv1x1_packed_floats(int cin, int cout) { return s3_packed(cin, cout, 1); }
 LIC360_API int lic360_sconv1x1_pack(void *stream, const float *weight, float *packed, int cin, int cout) { return s3_pack(stream, weight, packed, cin, cout, 1); }
 LIC360_API int lic360_sconv1x1(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                               int n, int cin, int cout, int hp, int wp, int ring, int ring_w) {
-    return s3_launch(stream, x, packed, bias, slope, residual, out, n, cin, cout, hp, wp, 0, 0, ring, ring_w, 0, 1);
+                               int n, int cin, int cout, int hp, int wp, int ring, int ring_w, int crop, int shuffle) {
+    return s3_launch(stream, x, packed, bias, slope, residual, out, n, cin, cout, hp, wp, 0, 0, ring, ring_w, crop, 1, shuffle);
 }

@@ -229,6 +229,14 @@ class ResidualBlockUp(nn.Module):
             b = self.relu2(lic360.sconv3x3(b, _packed(self.conv2), self.conv2.bias, None, None, b2, pad=2, sphere=True, ring=2))
         else:
             b = self.relu2(self.conv2(self.pad2(b)))
+        c_in, c_out = self.short_cut.in_channels, self.short_cut.out_channels
+        if (_fusable(self.conv2, b, 2) and x.is_contiguous() and b.is_contiguous() and lic360.sconv1x1_supported(c_in, c_out) and self.short_cut.bias is not None
+                and tuple(b.shape) == (x.shape[0], c_out // 4, 2 * (x.shape[2] - 2), 2 * (x.shape[3] - 2))):
+            # the shortcut -- cut_edge(1) -> 1x1 conv to 4c -> Dtow(2) -- and the `b +` in one launch: the 1x1 instantiation with the shuffled store,
+            # b as its (shuffled) residual, on the interior window (trim2 zeroes the rest)
+            out = torch.empty_like(b)
+            lic360.sconv1x1(x, _packed(self.short_cut), self.short_cut.bias, None, b, out, ring=2, crop=1, shuffle=True)
+            return self.trim2(out)
         return self.trim2(b + self.dtow2(self.short_cut(self.cut_edge(x))))
 
 

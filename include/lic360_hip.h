@@ -329,13 +329,15 @@ int lic360_sconv3x3_pack(void *stream, const float *weight, float *packed, int c
 int lic360_sconv3x3(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
                     int n, int cin, int cout, int hp, int wp, int pad, int sphere, int ring, int ring_w, int crop, int shuffle);
 /* the transforms' 1x1 layers on the same kernel body (K = input channels only): replaces nn.Conv2d(c, c', 1) + nn.PReLU (+ residual add) of
- * test/model_zoo.py:8-23 (ResidualBlock.conv1 / conv3).  x / residual / out [n][.][hp][wp]; the cells of rows [ring, hp - ring) x columns
- * [ring_w, wp - ring_w) are written, the others not touched; cin % 32 == 0, cout = 96 or a multiple of 192 */
+ * test/model_zoo.py:8-23 (ResidualBlock.conv1 / conv3) and, with crop = 1 and shuffle != 0, SphereCutEdge(1) + nn.Conv2d(c, 4c, 1) + Dtow(2) (+ add) of
+ * the shortcut of ResidualBlockUp (test/model_zoo.py:165-168).  x [n][cin][hp][wp]; out (and residual) [n][cout][hp - 2 crop][wp - 2 crop], or shuffled
+ * [n][cout / 4][2 (hp - 2 crop)][2 (wp - 2 crop)]; the cells of rows [ring, hp - ring) x columns [ring_w, wp - ring_w) of the input grid are written, the
+ * others not touched; cin % 32 == 0, cout = 96 or a multiple of 192 */
 int lic360_sconv1x1_supported(int cin, int cout);
 long lic360_sconv1x1_packed_floats(int cin, int cout);
 int lic360_sconv1x1_pack(void *stream, const float *weight, float *packed, int cin, int cout);
 int lic360_sconv1x1(void *stream, const float *x, const float *packed, const float *bias, const float *slope, const float *residual, float *out,
-                    int n, int cin, int cout, int hp, int wp, int ring, int ring_w);
+                    int n, int cin, int cout, int hp, int wp, int ring, int ring_w, int crop, int shuffle);
 /* apron of dst <- sphere-wrapped interior of src (src == dst: lic360_sphere_pad_inplace); [nc][hp][wp] planes      sphere_pad_cuda.cu:48-65 */
 int lic360_sphere_apron_from(void *stream, const float *src, float *dst, int nc, int hp, int wp, int pad);
 
