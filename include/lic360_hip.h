@@ -174,6 +174,14 @@ long lic360_conv4_packed_floats(const lic360_conv_plan *plan);
 int lic360_conv4_pack(void *stream, const lic360_conv_plan *plan, const float *weight, int nb, float *packed4);
 int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *plan, const float *x, const float *packed4, const float *bias,
                            const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod);
+/* Host-only (no GPU work): the sample packing lic360_cconv4_dc_plane uses on plane psum for a layer of ngroup groups (cin = 4: hidden / last
+ * layers, 1: first layer) over n samples of nb nets -- "tape" packing: the row windows of *tape_c consecutive samples of an XCD's list laid end to
+ * end over the 64 lanes of nwaves[j] tasks per group block j (a window may be cut between two tasks).  *tape_c = 0: one sample per task on this
+ * plane.  blocks[j] = first group of block j (launch order); windows[(j * 6 + t) * 3 + i] = piece i of task t of a tape:
+ * k | slo << 3 | shi << 9 | a0 << 15 | 1 << 21 (sample k of the tape stores rows slo..shi from lanes a0..; 0 = none).  Arrays of 24, 24 and
+ * 24 * 6 * 3 entries.  For tests of the packing rules (tests/test_dc_tape.py). */
+int lic360_dc4_tape_layout(int ngroup, int cin, int n, int nb, int h, int w, int psum, int x_mod, int *tape_c, int *n_blocks, int *blocks,
+                           int *nwaves, unsigned *windows);
 
 /* Encode-order variant on v_mfma_f32_16x16x4_f32 (csrc/cconv16_kernels.hip): rows = 4 consecutive groups x 4 output channels, K = 4
  * consecutive input groups of a lane's chain; same results bit for bit as lic360_cconv_ec (extension/cconv_ec_cuda.cu:271-331).

@@ -915,14 +915,18 @@ def test_cconv16_last_layer_with_fused_tables(lic, G, B, H, W):
                                   (15, 4, False, True, 2, 32, 30, 30), (8, 4, True, True, 3, 3, 6, 9), (48, 4, True, True, 3, 48, 8, 16),
                                   (48, 3, True, False, 3, 6, 64, 20), (4, 4, False, True, 1, 1, 33, 40), (4, 3, True, False, 2, 96, 30, 6),
                                   (20, 2, True, True, 2, 34, 17, 3), (48, 4, True, True, 3, 48, 64, 7), (16, 4, True, True, 1, 17, 50, 30),
-                                  (8, 4, False, True, 3, 144, 33, 21)],
-                         ids=lambda c: "g%d_4to%d_%s_n%d_%dx%d" % (c[0], c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
+                                  (8, 4, False, True, 3, 144, 33, 21), (12, 4, True, True, 1, 40, 50, 12), (12, 4, True, True, 2, 64, 33, 9),
+                                  (9, 4, True, True, 1, 72, 64, 30), (12, 3, True, False, 1, 144, 61, 23), (48, 4, False, True, 3, 48, 64, 20, 1),
+                                  (12, 4, False, True, 1, 40, 50, 12, 1), (8, 4, False, True, 3, 3, 20, 9, 1)],
+                         ids=lambda c: "g%d_%dto%d_%s_n%d_%dx%d" % (c[0], c[8] if len(c) > 8 else 4, c[1], "h" if c[2] else "f", c[5], c[6], c[7]))
 def test_cconv4_dc_planes_packed_bit_exact(lic, case):
-    """the production decode kernel (4x4x1 MFMAs, lic360_cconv4_dc_plane) plane by plane with its sample packing: THREE samples per task on the
-    corner diagonals that fit 14 rows (24 | samples per net: lanes 0..15 / 20..35 / 40..55, top and bottom windows), two per task where they
-    fit 26 rows (16 | samples per net), both in one launch (48 per net), neither (the middle diagonals); every case has more than 128 three-group
-    tasks per launch (fewer switch the kernel to its one-group-per-task latency mode, which does not pack); from the fifth case on: few samples
-    (latency mode), odd sample counts, cout = 2 / 3, first-layer constraint, widths below 5, 64-row diagonals, 144 samples"""
+    """the production decode kernel (4x4x1 MFMAs, lic360_cconv4_dc_plane) plane by plane with its sample packing -- TAPE packing (round 5): the
+    row windows of 2..6 consecutive samples of an XCD's list laid end to end over the lanes of as few tasks as fit, windows cut between tasks
+    where they do not (tests/test_dc_tape.py checks the host side's rules on the CPU); blocks of full-length diagonals keep one sample per task
+    inside the same launch.  Cases: tapes of 6 (48 / 144 samples per net), 2 (16), 5 (40), 4 (32), 3 (72: nine per list) samples; short, 64-row
+    and 61-row (odd, cut) diagonals; every case has more than 128 three-group tasks per launch (fewer switch the kernel to its
+    one-group-per-task latency mode, which does not pack); from the fifth case on also few samples (latency mode), odd sample counts,
+    cout = 2 / 3, first-layer constraint, widths below 5, 144 samples; the last three: the FIRST layer's instantiation (cin = 1)"""
     _cconv4_dc_planes(lic, case, "lic360_cconv4_dc_plane", ("lic360_conv4_supported", "lic360_conv4_packed_floats", "lic360_conv4_pack"))
 
 
@@ -930,9 +934,10 @@ def _cconv4_dc_planes(lic, case, entry, packfns):
     """one decode-order layer of the latent nets on the lic360_dc4_layout, plane by plane: after every checked plane the persistent output
     equals the oracle's (extension/cconv_dc_cuda.cu:313-398) + residual"""
     import ctypes as C
-    G, cout, hidden, act, nb, N, H, W = case
+    G, cout, hidden, act, nb, N, H, W = case[:8]
+    cin = case[8] if len(case) > 8 else 4
     rng = np.random.default_rng(1000 + 7 * G + 131 * N + 17 * H + W)
-    Cc, nout = G * 4, G * cout
+    Cc, nout = G * cin, G * cout
     w, b, a = conv_params(rng, nb if nb > 1 else None, nout, Cc, act=act)
     if nb == 1:
         w, b = w[None], b[None]
