@@ -132,6 +132,8 @@ struct I144Args {
     const float *x, *packed, *bias, *act, *residual;
     float *out;
     int N, H, W, nout, n_ot;
+    int grid;                                   // workgroups of the launch (reading gridDim would add HIP's 256 bytes of implicit kernel arguments to every launch:
+                                                //   argument bytes cost time when several streams launch at once, DESIGN.md 4.1 b'')
     long xplane, xsample;                       // floats per input plane / sample
     int xpitch;
     long oplane, osample;                       // output (and residual) addressing: plane / sample strides,
@@ -174,7 +176,7 @@ __device__ __forceinline__ void i144_body(const I144Args &a, float *xs, float *c
     const int kq = lane >> 4, j = lane & 15;
     const int ntasks = DC ? a.N * a.n_og * a.n_seg : a.N * a.tiles_r * a.tiles_c;
     int parity = 0;
-    for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    for (int task = blockIdx.x; task < ntasks; task += a.grid) {
         // ---- task geometry
         int n, r0 = 0, c0 = 0, ot_lo = 0, ot_hi = a.n_ot, th0 = 0;
         if constexpr (DC) {
@@ -324,6 +326,7 @@ LIC360_API int lic360_cconv144_ec(void *stream, const lic360_conv_plan *p, const
     a.s = a.th_lo = a.th_hi = a.th0 = 0; a.og = a.n_ot; a.n_og = 1; a.n_seg = 1;
     const long ntasks = (long)n * a.tiles_r * a.tiles_c;
     const dim3 grid((unsigned)(ntasks < 256 ? ntasks : 256));
+    a.grid = (int)grid.x;
     hipLaunchKernelGGL((k_cconv144<1, false, I144_NT_EC>), grid, dim3(I144_THREADS), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return 0;
@@ -357,6 +360,7 @@ LIC360_API int lic360_cconv144_dc_plane(void *stream, const lic360_conv_plan *p,
     a.n_og = (a.n_ot + a.og - 1) / a.og;
     const long ntasks = (long)n * a.n_og * a.n_seg;
     const dim3 grid((unsigned)(ntasks < 256 ? ntasks : 256));
+    a.grid = (int)grid.x;
     hipLaunchKernelGGL((k_cconv144<1, true, I144_NT_DC>), grid, dim3(I144_THREADS), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();
     return 0;

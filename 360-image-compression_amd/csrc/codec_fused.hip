@@ -1078,7 +1078,9 @@ __global__ void k_imp_mask_plane(const float *__restrict__ levels, const int *__
                                  int B, int H, int W, int C, int s, int cpn) {
     const long HW = (long)H * W, total = (long)B * len * C;
     const int Co = C / (s * s), Ho = H * s, Wo = W * s;
-    GRID_STRIDE(e, total) {
+    // one thread per element, 256 threads per workgroup (launched once per plane: no gridDim / blockDim, so no implicit kernel arguments)
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < total) {
         const int tc = (int)(e % C), i = (int)((e / C) % len), b = (int)(e / C / len);
         const int th = idx[start + i], tw = idx[start + i + HW];
         const int imp = (int)((double)levels[(long)b * HW + (long)th * W + tw] + 1e-5) * cpn;
@@ -1128,7 +1130,7 @@ static int impcodec_decode_impl(void *stream, lic360_impcodec *c, const uint8_t 
             // the latent mask of the map cells decoded in this plane (cells of later planes hold whatever the buffer held: nobody
             // reads their mask before their plane's event)
             const long tot = (long)B * len * mask_c;
-            hipLaunchKernelGGL(k_imp_mask_plane, dim3(lic360_blocks(tot, 1)), dim3(256), 0, s, levels_out, c->d_idx, start, len, mask_out, B, H, W,
+            hipLaunchKernelGGL(k_imp_mask_plane, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, levels_out, c->d_idx, start, len, mask_out, B, H, W,
                                mask_c, stride, mask_c / (c->nsym - 1));
             LAUNCH_CHECK();
             HIP_TRY(hipEventRecord(c->plane_ev[p], s));

@@ -179,7 +179,7 @@ int lic360_cconv4_dc_plane(void *stream, const lic360_conv_plan *plan, const flo
  * end over the 64 lanes of nwaves[j] tasks per group block j (a window may be cut between two tasks).  *tape_c = 0: one sample per task on this
  * plane.  blocks[j] = first group of block j (launch order); windows[(j * 6 + t) * 3 + i] = piece i of task t of a tape:
  * k | slo << 3 | shi << 9 | a0 << 15 | 1 << 21 (sample k of the tape stores rows slo..shi from lanes a0..; 0 = none).  Arrays of 24, 24 and
- * 24 * 6 * 3 entries.  For tests of the packing rules (tests/test_dc_tape.py). */
+ * 24 * 6 * 3 entries (the launch itself carries only where each task of a tape starts; the pieces follow from one rule on both sides).  For tests of the packing rules (tests/test_dc_tape.py). */
 int lic360_dc4_tape_layout(int ngroup, int cin, int n, int nb, int h, int w, int psum, int x_mod, int *tape_c, int *n_blocks, int *blocks,
                            int *nwaves, unsigned *windows);
 

@@ -7,7 +7,7 @@ for p in ("360-image-compression_amd", "tests"):
 import torch, numpy as np
 from util import latent, make_main_params
 from lic360_fused import FusedCodec
-G, H, W, B = 48, 64, 128, int(os.environ.get("PB", 32))
+G, H, W, B = 48, int(os.environ.get("XH", 64)), int(os.environ.get("XW", 128)), int(os.environ.get("PB", 32))
 layers = make_main_params(1003, G)
 fc = FusedCodec(G, H, W, max_batch=B); fc.load_layers(layers)
 items = [latent(np.random.default_rng(i), G, H, W) for i in range(B)]
