@@ -9,7 +9,9 @@ import csv
 import json
 import sys
 
-CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv16s", "ec_hidden"), ("k_cconv16<4, false>", "ec_hidden"),
+# (since round 5 the decode-order kernel has two names per layer type: k_cconv4v6t = the launches that tape-pack their samples, k_cconv4v6 = the others;
+#  a class sums over its kernels)
+CLASSES = [("k_cconv4v6<4, false", "dc_hidden"), ("k_cconv4v6t<4>", "dc_hidden"), ("k_cconv4v6<1, false", "dc_first"), ("k_cconv4v6t<1>", "dc_first"), ("k_cconv16s", "ec_hidden"), ("k_cconv16<4, false>", "ec_hidden"),
            ("k_cconv16<4, true>", "ec_last"), ("k_cconv16<1, false>", "ec_first"), ("k_cconv144<1, true", "imp_dc"), ("k_cconv144<1, false", "imp_ec"), ("k_imp_dc_map", "imp_dc_fused")]
 out_json, images = sys.argv[1], int(sys.argv[2])
 res = collections.defaultdict(dict)
@@ -22,10 +24,14 @@ for path in sys.argv[3:]:
         k = r["Kernel_Name"].replace("void ", "")
         tot[k] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
-    for k in tot:
+    acc = {}
+    for k in sorted(tot):
         for pat, cls in CLASSES:
             if k.startswith(pat):
-                res[cls][ctr] = {"kernel": k.split("(")[0], "launches": len(disp[k]), "per_launch_KB": tot[k] / len(disp[k])}
+                t = acc.setdefault(cls, {"kernel": [], "launches": 0, "KB": 0.0})
+                t["kernel"].append(k.split("(")[0]); t["launches"] += len(disp[k]); t["KB"] += tot[k]
+    for cls, t in acc.items():
+        res[cls][ctr] = {"kernel": " + ".join(t["kernel"]), "launches": t["launches"], "per_launch_KB": t["KB"] / t["launches"]}
 doc = {"command": "PB=%d rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/{dc,ec,imp}_probe.py (one encode + decodes of %d images, "
                   "single stream; separate passes per counter)" % (images, images),
        "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); Infinity-Cache hits are included in both counters; "
