@@ -608,6 +608,8 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
                 "images_per_launch": b0, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
                 "how": "one sub-batch alone on the GPU, one stream, HIP events around every launch on the launch stream (instrumented pass, "
                        "outside the timed region)",
+                "rocprof_kernel_names": "dc_hidden / dc_last launches run as k_cconv4v6t<4> (planes that tape-pack their samples) or k_cconv4v6<4, false, false> "
+                                        "(full-length planes); profiles/*_dc_isolated_kernel_stats.csv lists both, their call-weighted mean is this class",
                 "concurrent": {"avg_launch_ms": dom.get("avg_launch_ms_concurrent"), "streams": len(codecs),
                                "note": "same kernel while the other streams' kernels share the CUs (the timed region's regime)"},
                 "all_conv_layers_isolated": {"achieved": 2 * 2 * NET_GMAC * 1e9 * b0 / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
