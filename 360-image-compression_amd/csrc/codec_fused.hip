@@ -468,9 +468,42 @@ __device__ __forceinline__ void ac_state_check(AcState &s) {
 //                  output (= TileInput + `b[0:1] + 3.5*mask`, lic360_demo.py:222,236-237).  It needs < 40 VGPRs, so its
 //                  waves fit next to the 12-wave workgroups of the conv kernels of the other streams (456 of 512 VGPRs
 //                  per SIMD) instead of keeping whole CUs away from them for the ~0.4 ms the serial chain takes.
-__global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, const float *__restrict__ mask, const int *__restrict__ idx,
-                                                   int start, int len, int p, uint4 *__restrict__ tab, int tab_pitch,
-                                                   int B, int G, int H, int W, int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
+// one struct by value instead of 16 scalar kernel arguments: the number of arguments of a per-plane launch costs like their bytes do (DESIGN.md 4.1 b'')
+struct DecTablesArgs {
+    const float *y;
+    const float *mask;
+    const int *idx;
+    int start;
+    int len;
+    int p;
+    uint4 *tab;
+    int tab_pitch;
+    int B;
+    int G;
+    int H;
+    int W;
+    int sk_rows;
+    int sk_pitch;
+    int sk_row0;
+    int sk_col0;
+};
+__global__ __launch_bounds__(64) void k_dec_tables(const DecTablesArgs a) {
+    const float *__restrict__ y = a.y;
+    const float *__restrict__ mask = a.mask;
+    const int *__restrict__ idx = a.idx;
+    const int start = a.start;
+    const int len = a.len;
+    const int p = a.p;
+    uint4 *__restrict__ tab = a.tab;
+    const int tab_pitch = a.tab_pitch;
+    const int B = a.B;
+    const int G = a.G;
+    const int H = a.H;
+    const int W = a.W;
+    const int sk_rows = a.sk_rows;
+    const int sk_pitch = a.sk_pitch;
+    const int sk_row0 = a.sk_row0;
+    const int sk_col0 = a.sk_col0;
     const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
     if (i >= len) return;
     const int HW = H * W;
@@ -495,12 +528,49 @@ __global__ __launch_bounds__(64) void k_dec_tables(const float *__restrict__ y, 
 }
 
 // LINEAR (test hook lic360_devcoder_decode): symbols go to code_out[b*G + start + i] instead of the latent layouts
+// one struct by value instead of 19 scalar kernel arguments: the number of arguments of a per-plane launch costs like their bytes do (DESIGN.md 4.1 b'')
+struct DecPlaneArgs {
+    const uint4 *tab;
+    int tab_pitch;
+    const int *idx;
+    int start;
+    int len;
+    int p;
+    AcDevState *state;
+    const uint8_t *bytes;
+    long cap;
+    const int *nbytes;
+    float *x0;
+    float *code_out;
+    int G;
+    int H;
+    int W;
+    int sk_rows;
+    int sk_pitch;
+    int sk_row0;
+    int sk_col0;
+};
 template <bool LINEAR>
-__global__ __launch_bounds__(64) void k_dec_plane(const uint4 *__restrict__ tab, int tab_pitch, const int *__restrict__ idx,
-                                                  int start, int len, int p, AcDevState *__restrict__ state,
-                                                  const uint8_t *__restrict__ bytes, long cap, const int *__restrict__ nbytes,
-                                                  float *__restrict__ x0, float *__restrict__ code_out, int G, int H, int W,
-                                                  int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
+__global__ __launch_bounds__(64) void k_dec_plane(const DecPlaneArgs a) {
+    const uint4 *__restrict__ tab = a.tab;
+    const int tab_pitch = a.tab_pitch;
+    const int *__restrict__ idx = a.idx;
+    const int start = a.start;
+    const int len = a.len;
+    const int p = a.p;
+    AcDevState *__restrict__ state = a.state;
+    const uint8_t *__restrict__ bytes = a.bytes;
+    const long cap = a.cap;
+    const int *__restrict__ nbytes = a.nbytes;
+    float *__restrict__ x0 = a.x0;
+    float *__restrict__ code_out = a.code_out;
+    const int G = a.G;
+    const int H = a.H;
+    const int W = a.W;
+    const int sk_rows = a.sk_rows;
+    const int sk_pitch = a.sk_pitch;
+    const int sk_row0 = a.sk_row0;
+    const int sk_col0 = a.sk_col0;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int HW = H * W;
     const long SK = (long)sk_rows * sk_pitch;
@@ -770,12 +840,12 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
             const int q = std::min(n_gate - 1, p / gate_stride);
             if (q != gate_q) { HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)gate[q], 0)); gate_q = q; }
         }
-        PROF(c, PROF_DEC_TABLES, s, hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, mask, c->d_idx, start, len, p,
-                                                       c->d_tab, c->tab_pitch, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0));
+        PROF(c, PROF_DEC_TABLES, s, hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, DecTablesArgs{c->d_y, mask, c->d_idx, start, len, p,
+                                                       c->d_tab, c->tab_pitch, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0}));
         LAUNCH_CHECK();
-        PROF(c, PROF_DEC_PLANE, s, hipLaunchKernelGGL(k_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, p,
+        PROF(c, PROF_DEC_PLANE, s, hipLaunchKernelGGL(k_dec_plane<false>, dim3(B), dim3(64), 0, s, DecPlaneArgs{c->d_tab, c->tab_pitch, c->d_idx, start, len, p,
                                                       c->d_state, bytes, cap, nbytes, c->d_x0, code_out, G, H, W, c->sk_rows, c->sk_pitch,
-                                                      c->sk_row0, c->sk_col0));
+                                                      c->sk_row0, c->sk_col0}));
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
@@ -875,10 +945,37 @@ __global__ void k_imp_enc_tables(const float *__restrict__ y, const float *__res
 }
 // decode activations are diagonal-major [n][c][H+W-1][H] (cell (th, tw) at (th+tw)*H + th): the 16 plane positions a
 // conv wave gathers are contiguous
+// one struct by value instead of 13 scalar kernel arguments: the number of arguments of a per-plane launch costs like their bytes do (DESIGN.md 4.1 b'')
+struct ImpDecTablesArgs {
+    const float *y;
+    const int *idx;
+    int start;
+    int len;
+    int *tab;
+    int tab_pitch;
+    int H;
+    int W;
+    int nsym;
+    int sk_rows;
+    int sk_pitch;
+    int sk_row0;
+    int sk_col0;
+};
 template <bool FAST>
-__global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__ y, const int *__restrict__ idx, int start, int len,
-                                                       int *__restrict__ tab, int tab_pitch, int H, int W, int nsym,
-                                                       int sk_rows, int sk_pitch, int sk_row0, int sk_col0) {
+__global__ __launch_bounds__(64) void k_imp_dec_tables(const ImpDecTablesArgs a) {
+    const float *__restrict__ y = a.y;
+    const int *__restrict__ idx = a.idx;
+    const int start = a.start;
+    const int len = a.len;
+    int *__restrict__ tab = a.tab;
+    const int tab_pitch = a.tab_pitch;
+    const int H = a.H;
+    const int W = a.W;
+    const int nsym = a.nsym;
+    const int sk_rows = a.sk_rows;
+    const int sk_pitch = a.sk_pitch;
+    const int sk_row0 = a.sk_row0;
+    const int sk_col0 = a.sk_col0;
     const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
     if (i >= len) return;
     const long HW = (long)H * W, SK = (long)sk_rows * sk_pitch;
@@ -896,11 +993,49 @@ __global__ __launch_bounds__(64) void k_imp_dec_tables(const float *__restrict__
     }
 }
 // one wave per image: lane k holds T[k] of the current symbol; the symbol is the number of inner entries <= target
+// one struct by value instead of 19 scalar kernel arguments: the number of arguments of a per-plane launch costs like their bytes do (DESIGN.md 4.1 b'')
+struct ImpDecPlaneArgs {
+    const int *tab;
+    int tab_pitch;
+    const int *idx;
+    int start;
+    int len;
+    AcDevState *state;
+    const uint8_t *bytes;
+    long cap;
+    const int *nbytes;
+    float *x0;
+    float *out;
+    int H;
+    int W;
+    int nsym;
+    float sc;
+    int sk_rows = 0;
+    int sk_pitch = 0;
+    int sk_row0 = 0;
+    int sk_col0 = 0;
+};
 template <bool LINEAR>
-__global__ __launch_bounds__(64) void k_imp_dec_plane(const int *__restrict__ tab, int tab_pitch, const int *__restrict__ idx, int start, int len,
-                                                      AcDevState *__restrict__ state, const uint8_t *__restrict__ bytes, long cap,
-                                                      const int *__restrict__ nbytes, float *__restrict__ x0, float *__restrict__ out,
-                                                      int H, int W, int nsym, float sc, int sk_rows = 0, int sk_pitch = 0, int sk_row0 = 0, int sk_col0 = 0) {
+__global__ __launch_bounds__(64) void k_imp_dec_plane(const ImpDecPlaneArgs a) {
+    const int *__restrict__ tab = a.tab;
+    const int tab_pitch = a.tab_pitch;
+    const int *__restrict__ idx = a.idx;
+    const int start = a.start;
+    const int len = a.len;
+    AcDevState *__restrict__ state = a.state;
+    const uint8_t *__restrict__ bytes = a.bytes;
+    const long cap = a.cap;
+    const int *__restrict__ nbytes = a.nbytes;
+    float *__restrict__ x0 = a.x0;
+    float *__restrict__ out = a.out;
+    const int H = a.H;
+    const int W = a.W;
+    const int nsym = a.nsym;
+    const float sc = a.sc;
+    const int sk_rows = a.sk_rows;
+    const int sk_pitch = a.sk_pitch;
+    const int sk_row0 = a.sk_row0;
+    const int sk_col0 = a.sk_col0;
     const int b = blockIdx.x, lane = threadIdx.x;
     const long HW = (long)H * W;
     AcDevState ds = state[b];
@@ -1074,8 +1209,32 @@ LIC360_API int lic360_impcodec_encode(void *stream, lic360_impcodec *c, const fl
 // mask_out cells of the map positions idx[start .. start+len): Dtow(stride)(Imp2mask(levels)) restricted to them --
 //   tmask(tc, th, tw) = tc < int(level + 1e-5) * cpn                                 (extension/imp2mask_cuda.cu:31)
 //   out(pc, ph, pw)   = tmask(pc s^2 + (ph % s) s + pw % s, ph / s, pw / s)          (extension/dtow_cuda.cu:38-56)
-__global__ void k_imp_mask_plane(const float *__restrict__ levels, const int *__restrict__ idx, int start, int len, float *__restrict__ out,
-                                 int B, int H, int W, int C, int s, int cpn) {
+// one struct by value instead of 11 scalar kernel arguments: the number of arguments of a per-plane launch costs like their bytes do (DESIGN.md 4.1 b'')
+struct ImpMaskPlaneArgs {
+    const float *levels;
+    const int *idx;
+    int start;
+    int len;
+    float *out;
+    int B;
+    int H;
+    int W;
+    int C;
+    int s;
+    int cpn;
+};
+__global__ void k_imp_mask_plane(const ImpMaskPlaneArgs a) {
+    const float *__restrict__ levels = a.levels;
+    const int *__restrict__ idx = a.idx;
+    const int start = a.start;
+    const int len = a.len;
+    float *__restrict__ out = a.out;
+    const int B = a.B;
+    const int H = a.H;
+    const int W = a.W;
+    const int C = a.C;
+    const int s = a.s;
+    const int cpn = a.cpn;
     const long HW = (long)H * W, total = (long)B * len * C;
     const int Co = C / (s * s), Ho = H * s, Wo = W * s;
     // one thread per element, 256 threads per workgroup (launched once per plane: no gridDim / blockDim, so no implicit kernel arguments)
@@ -1117,21 +1276,21 @@ static int impcodec_decode_impl(void *stream, lic360_impcodec *c, const uint8_t 
         const int start = pih[p], len = pih[p + 1] - pih[p];
         if (len <= 0) continue;
         if (c->nsym == IMP_NSYM_FAST)
-            hipLaunchKernelGGL(k_imp_dec_tables<true>, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
-                               c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+            hipLaunchKernelGGL(k_imp_dec_tables<true>, dim3((len + 63) / 64, B), dim3(64), 0, s, ImpDecTablesArgs{c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
+                               c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0});
         else
-            hipLaunchKernelGGL(k_imp_dec_tables<false>, dim3((len + 63) / 64, B), dim3(64), 0, s, c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
-                               c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+            hipLaunchKernelGGL(k_imp_dec_tables<false>, dim3((len + 63) / 64, B), dim3(64), 0, s, ImpDecTablesArgs{c->d_y, c->d_idx, start, len, c->d_tab, c->tab_pitch, H, W, c->nsym,
+                               c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0});
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_imp_dec_plane<false>, dim3(B), dim3(64), 0, s, c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
-                           c->d_x0, levels_out, H, W, c->nsym, c->sc, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0);
+        hipLaunchKernelGGL(k_imp_dec_plane<false>, dim3(B), dim3(64), 0, s, ImpDecPlaneArgs{c->d_tab, c->tab_pitch, c->d_idx, start, len, c->d_state, bytes, cap, nbytes,
+                           c->d_x0, levels_out, H, W, c->nsym, c->sc, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0});
         LAUNCH_CHECK();
         if (mask_out) {
             // the latent mask of the map cells decoded in this plane (cells of later planes hold whatever the buffer held: nobody
             // reads their mask before their plane's event)
             const long tot = (long)B * len * mask_c;
-            hipLaunchKernelGGL(k_imp_mask_plane, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, levels_out, c->d_idx, start, len, mask_out, B, H, W,
-                               mask_c, stride, mask_c / (c->nsym - 1));
+            hipLaunchKernelGGL(k_imp_mask_plane, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, ImpMaskPlaneArgs{levels_out, c->d_idx, start, len, mask_out, B, H, W,
+                               mask_c, stride, mask_c / (c->nsym - 1)});
             LAUNCH_CHECK();
             HIP_TRY(hipEventRecord(c->plane_ev[p], s));
         }
@@ -1273,13 +1432,13 @@ LIC360_API int lic360_devcoder_decode(void *stream, const int *tables, int ncode
         if (ncode == 8) {
             hipLaunchKernelGGL(k_test_tab8, dim3((len + 63) / 64), dim3(64), 0, s, tables, mask, start, len, tab8, st);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_dec_plane<true>, dim3(1), dim3(64), 0, s, tab8, chunk, (const int *)nullptr, (int)start, len, 0, st, bytes, cap, nbytes,
-                               (float *)nullptr, out, 0, 1, 1, 0, 0, 0, 0);
+            hipLaunchKernelGGL(k_dec_plane<true>, dim3(1), dim3(64), 0, s, DecPlaneArgs{tab8, chunk, (const int *)nullptr, (int)start, len, 0, st, bytes, cap, nbytes,
+                               (float *)nullptr, out, 0, 1, 1, 0, 0, 0, 0});
         } else {
             hipLaunchKernelGGL(k_test_tabn, dim3(len), dim3(64), 0, s, tables, ncode, start, len, tabn);
             LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_imp_dec_plane<true>, dim3(1), dim3(64), 0, s, tabn, chunk, (const int *)nullptr, (int)start, len, st, bytes, cap, nbytes,
-                               (float *)nullptr, out, 0, 0, ncode, 0.0f);
+            hipLaunchKernelGGL(k_imp_dec_plane<true>, dim3(1), dim3(64), 0, s, ImpDecPlaneArgs{tabn, chunk, (const int *)nullptr, (int)start, len, st, bytes, cap, nbytes,
+                               (float *)nullptr, out, 0, 0, ncode, 0.0f});
         }
         LAUNCH_CHECK();
     }
