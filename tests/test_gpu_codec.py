@@ -83,10 +83,12 @@ def test_cast_entropy_parameter():
                                           (3, 130, 8, 1, 18),      # three row segments, the last one 6 rows
                                           (4, 64, 6, 1, 15),       # W < 7: row-major encode kernel, diagonal decode kernel
                                           (3, 66, 68, 1, 17),      # H, W > 64 (the 1024x2048 regime)
-                                          (4, 64, 12, 16, 19),     # 16 images: short diagonals at both image corners carry two samples per wave
+                                          (4, 64, 12, 16, 19),     # 16 images: short diagonals at both image corners carry two samples per wave (tapes of 2)
                                           (6, 8, 12, 16, 20),      # every diagonal short: all decode tasks carry two samples
                                           (3, 130, 8, 16, 21),     # three row segments, the last (6 rows) with two samples per wave
-                                          (4, 66, 10, 16, 22)])    # two row segments, the last (4 rows) packed
+                                          (4, 66, 10, 16, 22),     # two row segments, the last (4 rows) packed
+                                          (6, 28, 40, 24, 23),     # 8 | images: the decode kernel tape-packs its samples (tapes of 3; round 5)
+                                          (6, 50, 12, 40, 24)])    # ... tapes of 5, windows cut between tasks
 def test_fused_codec_matches_oracle(G, H, W, B, seed):
     """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode."""
     from lic360_fused import FusedCodec
