@@ -169,7 +169,12 @@ struct C16Args {
     const float *code, *mask;                  // [N, G, H, W] symbols / importance mask
     const int *pidx, *plane_start;             // scan-order prefix tables (code_contex_cuda.cu:19-31) / first record of a plane
     uint2 *rec;                                // [N][G*H*W] (cdf[sym], cdf[sym+1]) in coding order
+    // dead-cone skip (round 6, need.h): per XCD the live tasks of this layer in launch order, entry = u | tile mask << 28 (list[xcd * list_cap + k], cnt[xcd]
+    // entries); NULL: every task, every tile
+    const int *list, *cnt;
+    int list_cap;
 };
+#define C16_TASK_END 0x0fffffff              // task number of a ring entry past the end of the XCD's list
 
 #ifdef C16_STAMP
 // diagnostic build only (tools/ec_stamp.sh): cycles per phase of the hidden-layer instantiation, summed per wave over the launches
@@ -318,8 +323,21 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     // ---- task queue: thread 0 pulls task numbers four tasks ahead of the compute cursor into an 8-slot LDS ring
     // (the issue cursor runs two steps ahead: with one-step tasks it reads task c + 3 while the compute cursor is in task c,
     // and a barrier must lie between a pull and its first read)
-    auto pull = [&](int k) __attribute__((always_inline)) { if (tid == 0) tq[k & 7] = atomicAdd(a.ctr + xcd, 1); };
-    auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]); };
+    // ring entry = task number u | tile mask << 28 (bit t: tile t of the task's chunk is live).  With a list (a.list: the dead-cone skip, need.h) the
+    // counter indexes the XCD's compacted list of live tasks; without one every task is live with all its tiles.
+    const int n_live = a.list ? __builtin_amdgcn_readfirstlane(a.cnt[xcd]) : n_my;   // entries of this XCD's list
+    auto pull = [&](int k) __attribute__((always_inline)) {
+        if (tid == 0) {
+            const int i = atomicAdd(a.ctr + xcd, 1);
+            tq[k & 7] = i < n_live ? (a.list ? a.list[(long)xcd * a.list_cap + i] : (int)((unsigned)i | 0xfu << 28)) : C16_TASK_END;
+        }
+    };
+    auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]) & 0x0fffffff; };
+    // the live tiles of ring entry k (clamped to the tiles that exist: tile0 = the chunk's first tile)
+    auto tmask = [&](int k, int tile0) __attribute__((always_inline)) {
+        const int nt = a.ntiles - tile0 < TPT ? a.ntiles - tile0 : TPT;
+        return (int)(((unsigned)__builtin_amdgcn_readfirstlane(tq[k & 7]) >> 28) & ((1u << nt) - 1u));
+    };
     // task u -> sample n, first tile, group block (group block fastest: the workgroups of an XCD share the input region)
     auto decode = [&](int u, int &n, int &tile0, int &gb) __attribute__((always_inline)) {
         const int units = ns_x * a.n_chunks, per = a.gbk * a.n_gb, blk = u / per, r = u - blk * per;
@@ -382,7 +400,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
     const bool ragged = C % (TCS * CIN) != 0;                               // the last step holds fewer than 16 planes
     const unsigned lds_base = c16_lds_addr(lds);
     // ---- issue cursor
-    int iq = 0, itile = 0, istep = 0, inet = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;
+    int iq = 0, i_rem = 0, i_mask0 = 0, istep = 0, inet = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;   // i_rem: live tiles of the task still to issue
     bool ivalid = false;
     const float *ixb = a.x, *iwb = a.packed;                                // x of (sample, tile), weights of (net, group block)
     auto issue_task = [&]() __attribute__((always_inline)) {
@@ -390,12 +408,13 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         ivalid = u < n_my;
         if (ivalid) {
             decode(u, i_n, i_tile0, i_gb);
+            i_mask0 = i_rem = tmask(iq, i_tile0);
             i_nsteps = steps_of(i_gb);
             if constexpr (!FUSE) iwb = a.packed + ((long)(i_n / a.npb) * a.n_gb + i_gb) * a.NS * C16_WFL;
         }
     };
     auto issue_tile = [&]() __attribute__((always_inline)) {
-        const int T = i_tile0 + itile, ty = T / a.ntx, tx = T - ty * a.ntx;
+        const int T = i_tile0 + __builtin_ctz(i_rem), ty = T / a.ntx, tx = T - ty * a.ntx;
         const int sample = FUSE ? inet * a.N + i_n : i_n;                   // FUSE: sample of net `inet` = inet * images + image
         ixb = a.x + (long)(sample % a.x_mod) * C * PL + (long)(ty * C16_TH) * a.wp + tx * C16_TW;
         if constexpr (FUSE) iwb = a.packed + ((long)inet * a.n_gb + i_gb) * a.NS * C16_WFL;
@@ -434,10 +453,10 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         if (ivalid) {
             if (++istep == i_nsteps) {
                 istep = 0;
+                i_rem &= i_rem - 1;
                 if constexpr (FUSE) {                                       // tile fastest, then net, then the next task
-                    ++itile;
-                    if (itile == TPT || i_tile0 + itile >= a.ntiles) {
-                        itile = 0;
+                    if (!i_rem) {
+                        i_rem = i_mask0;
                         if (++inet == NSUB) {
                             inet = 0;
                             ++iq;
@@ -445,15 +464,13 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                         }
                     }
                 } else {
-                    ++itile;
-                    if (itile == TPT || i_tile0 + itile >= a.ntiles) {
-                        itile = 0;
+                    if (!i_rem) {
                         ++iq;
                         issue_task();
                     }
                 }
                 if (ivalid) issue_tile();
-                else { istep = i_nsteps - 1; inet = NSUB - 1; itile = 0; }     // idle: stay on the last step
+                else { istep = i_nsteps - 1; inet = NSUB - 1; }             // idle: stay on the last step
             }
         }
     };
@@ -469,8 +486,9 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         issue(1);
     }
     // ---- compute cursor
-    int cq = 0, ctile = 0, cstep = 0, cnet = 0, c_nsteps, c_tile0, c_n, c_gb;
+    int cq = 0, ctile = 0, cstep = 0, cnet = 0, c_nsteps, c_tile0, c_n, c_gb;   // ctile: live tiles of the task done (FUSE: the y slot of the current one)
     decode(task(0), c_n, c_tile0, c_gb);
+    int c_mask0 = tmask(0, c_tile0), c_rem = c_mask0;                       // c_rem: live tiles of the task still to compute; the current one is its lowest bit
     c_nsteps = steps_of(c_gb);
     f32x4 acc[C16_NT][NA];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -514,7 +532,7 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
         // three dependent memory round trips per tile, ~25 % of the kernel)
         const bool last = cstep + 1 == c_nsteps;
         if (last) {
-            const int T = c_tile0 + ctile, ty = T / a.ntx, tx = T - ty * a.ntx;
+            const int T = c_tile0 + __builtin_ctz(c_rem), ty = T / a.ntx, tx = T - ty * a.ntx;
             const int q = lane >> 4, j = lane & 15;
             const int y = ty * C16_TH + (WAVE >> 1), x = tx * C16_TW + j, g = c_gb * 4 + q;
             e_ok = g < G && y < a.H && x < a.W;
@@ -637,20 +655,23 @@ __device__ __forceinline__ void c16_body(const C16Args &a, float *lds, float *co
                 if (c_nsteps == 1) __syncthreads();                         // one-step tiles: the single comb buffer is rewritten before the next barrier
             }
             ++ctile;
-            bool task_done = ctile == TPT || c_tile0 + ctile >= a.ntiles;
+            c_rem &= c_rem - 1;
+            bool task_done = c_rem == 0;
             if constexpr (FUSE) {
+                static_assert(TPT == 2, "the live tiles of a fused task are consecutive (tables phase: tile tb_T + slot)");
                 if (task_done) {                                            // this net's sweep over the task's tiles is complete
                     const int nt = ctile;
                     ctile = 0;
+                    c_rem = c_mask0;
                     if (++cnet < NSUB) task_done = false;                   // the same tiles, next net
-                    else { cnet = 0; tb_pending = true; tb_T = c_tile0; tb_nt = nt; tb_n = c_n; tb_gb = c_gb; }
+                    else { cnet = 0; tb_pending = true; tb_T = c_tile0 + __builtin_ctz(c_mask0); tb_nt = nt; tb_n = c_n; tb_gb = c_gb; }
                 }
             } else if (task_done) ctile = 0;
             if (task_done) {
                 ++cq;
                 pull(cq + 4);                                               // first read at least one barrier later
                 const int u = task(cq);
-                if (u < n_my) { decode(u, c_n, c_tile0, c_gb); c_nsteps = steps_of(c_gb); }
+                if (u < n_my) { decode(u, c_n, c_tile0, c_gb); c_nsteps = steps_of(c_gb); c_mask0 = c_rem = tmask(cq, c_tile0); }
                 else done = true;
             }
         } else ++cstep;
@@ -729,8 +750,19 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
     unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long t_entry = t0;
 #endif
-    auto pull = [&](int k) __attribute__((always_inline)) { if (tid == 0) tq[k & 7] = atomicAdd(a.ctr + xcd, 1); };
-    auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]); };
+    // ring entries, the optional list of live tasks and the tile masks: as in c16_body
+    const int n_live = a.list ? __builtin_amdgcn_readfirstlane(a.cnt[xcd]) : n_my;   // entries of this XCD's list
+    auto pull = [&](int k) __attribute__((always_inline)) {
+        if (tid == 0) {
+            const int i = atomicAdd(a.ctr + xcd, 1);
+            tq[k & 7] = i < n_live ? (a.list ? a.list[(long)xcd * a.list_cap + i] : (int)((unsigned)i | 0xfu << 28)) : C16_TASK_END;
+        }
+    };
+    auto task = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(tq[k & 7]) & 0x0fffffff; };
+    auto tmask = [&](int k, int tile0) __attribute__((always_inline)) {
+        const int nt = a.ntiles - tile0 < TPT ? a.ntiles - tile0 : TPT;
+        return (int)(((unsigned)__builtin_amdgcn_readfirstlane(tq[k & 7]) >> 28) & ((1u << nt) - 1u));
+    };
     auto decode = [&](int u, int &n, int &tile0, int &gb) __attribute__((always_inline)) {
         const int units = ns_x * a.n_chunks, per = a.gbk * a.n_gb, blk = u / per, r = u - blk * per;
         const int left = units - blk * a.gbk, kk = left < a.gbk ? left : a.gbk;
@@ -781,7 +813,7 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
     const bool ragged = C % (TCS * CIN) != 0;
     const unsigned lds_base = c16_lds_addr(lds);
     // ---- issue cursor: one step image per epoch, the same step in both wave sets
-    int iq = 0, itile = 0, istep = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;
+    int iq = 0, i_rem = 0, istep = 0, i_nsteps = 0, i_tile0 = 0, i_n = 0, i_gb = 0;   // i_rem: live tiles of the task still to issue
     bool ivalid = false;
     const float *ixb = a.x, *iwb = a.packed;
     auto issue_task = [&]() __attribute__((always_inline)) {
@@ -789,12 +821,13 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
         ivalid = u < n_my;
         if (ivalid) {
             decode(u, i_n, i_tile0, i_gb);
+            i_rem = tmask(iq, i_tile0);
             i_nsteps = steps_of(i_gb);
             iwb = a.packed + ((long)(i_n / a.npb) * a.n_gb + i_gb) * a.NS * C16_WFL;
         }
     };
     auto issue_tile = [&]() __attribute__((always_inline)) {
-        const int T = i_tile0 + itile, ty = T / a.ntx, tx = T - ty * a.ntx;
+        const int T = i_tile0 + __builtin_ctz(i_rem), ty = T / a.ntx, tx = T - ty * a.ntx;
         ixb = a.x + (long)(i_n % a.x_mod) * C * PL + (long)(ty * C16_TH) * a.wp + tx * C16_TW;
     };
     auto issue_dma = [&](auto mm, int buf) __attribute__((always_inline)) {
@@ -816,14 +849,13 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
         if (ivalid) {
             if (++istep == i_nsteps) {
                 istep = 0;
-                ++itile;
-                if (itile == TPT || i_tile0 + itile >= a.ntiles) {
-                    itile = 0;
+                i_rem &= i_rem - 1;
+                if (!i_rem) {
                     ++iq;
                     issue_task();
                 }
                 if (ivalid) issue_tile();
-                else { istep = i_nsteps - 1; itile = 0; }                   // idle: stay on the last step
+                else istep = i_nsteps - 1;                                  // idle: stay on the last step
             }
         }
     };
@@ -836,8 +868,9 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
     issue_tile();
     issue_all(0);                                                           // step 0 -> buffer 0 (each set its share of the windows)
     // ---- compute cursor
-    int cq = 0, ctile = 0, cstep = 0, c_nsteps, c_tile0, c_n, c_gb;
+    int cq = 0, cstep = 0, c_nsteps, c_tile0, c_n, c_gb;
     decode(task(0), c_n, c_tile0, c_gb);
+    int c_rem = tmask(0, c_tile0);                                          // live tiles of the task still to compute; the current one is its lowest bit
     c_nsteps = steps_of(c_gb);
     f32x4 acc[C16_NT][NA];
     const int xlane = (lane >> 4) * 4 * C16_PLANE + (C16_NT * PS) * C16_HC + (lane & 15);
@@ -850,7 +883,7 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
     const float *const act_p = a.act ? a.act : a.bias, *const res_p = a.residual ? a.residual : a.x;
     // bias / PReLU slope / residual of the current tile (clamped addresses), fetched one epoch before the tile is finished
     auto prefetch_epilogue = [&]() __attribute__((always_inline)) {
-        const int T = c_tile0 + ctile, ty = T / a.ntx, tx = T - ty * a.ntx;
+        const int T = c_tile0 + __builtin_ctz(c_rem), ty = T / a.ntx, tx = T - ty * a.ntx;
         const int q = lane >> 4, j = lane & 15;
         const int y = ty * C16_TH + (WAVE >> 1), x = tx * C16_TW + j, g = c_gb * 4 + q;
         e_ok = g < G && y < a.H && x < a.W;
@@ -896,13 +929,12 @@ __device__ __forceinline__ void c16s_body(const C16Args &a, float *lds, float *c
         if (last) {
             cstep = 0;
             ++ntile;
-            ++ctile;
-            if (ctile == TPT || c_tile0 + ctile >= a.ntiles) {
-                ctile = 0;
+            c_rem &= c_rem - 1;
+            if (!c_rem) {
                 ++cq;
                 if constexpr (PS == 0) pull(cq + 4);                        // first read at least one barrier later
                 const int u = task(cq);
-                if (u < n_my) { decode(u, c_n, c_tile0, c_gb); c_nsteps = steps_of(c_gb); }
+                if (u < n_my) { decode(u, c_n, c_tile0, c_gb); c_nsteps = steps_of(c_gb); c_rem = tmask(cq, c_tile0); }
                 else done = true;
             }
         } else ++cstep;
@@ -1045,17 +1077,24 @@ static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w, in
     a.NS = conv16_nsteps_max(p);
     a.gbk = 16;                                                             // task-order block size (blocks of 4 .. all measured: DESIGN 4.1 a)
     a.code = a.mask = nullptr; a.pidx = a.plane_start = nullptr; a.rec = nullptr;
+    a.list = a.cnt = nullptr; a.list_cap = 0;
     return 0;
 }
 
 // x / residual / out: [n][C | nout][hp][wp] zero-haloed planes (lic360_ec16_layout).  ctr: 8 ints of device scratch.
-LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
-                                 const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr) {
+// list / cnt / cap: the layer's live tasks per XCD (need.h, lic360_ec_lists_build: [8][cap] entries, [8] counts), or NULL = every task.  The cells of
+// a skipped (tile, group block) are not written.  Internal entry (hidden visibility): the fused codec's dead-cone skip.
+int lic360_cconv16_ec_list(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                           const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr,
+                           const int *list, const int *cnt, int cap) {
     ARG_CHECK(p && conv16_ok(p) && x && packed16 && bias && out && ctr && n > 0 && h > 0 && w > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
+    ARG_CHECK((list != nullptr) == (cnt != nullptr) && (!list || (cap > 0 && p->cin == 4)));
     C16Args a;
     a.x = x; a.packed = packed16; a.bias = bias; a.act = act; a.residual = residual; a.out = out; a.ctr = ctr;
     a.npb = n / nb; a.x_mod = x_mod; a.N = n;
     if (c16_fill_args(a, p, h, w)) return 2;
+    a.list = list; a.cnt = cnt; a.list_cap = cap;
+    ARG_CHECK((long)((n + 7) / 8) * a.n_chunks * a.n_gb < C16_TASK_END);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));
     // cin = 4: the skewed form (k_cconv16s) when every tile has at least two steps; nets of fewer than five groups keep the lockstep kernel
@@ -1066,6 +1105,10 @@ LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const 
     LAUNCH_CHECK();
     return 0;
 }
+LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                                 const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr) {
+    return lic360_cconv16_ec_list(stream, p, x, packed16, bias, act, residual, out, n, h, w, nb, x_mod, ctr, nullptr, nullptr, 0);
+}
 
 // Last layer of the latent entropy model fused with the CDF-table build (SURVEY.md §7 `k_cconv_ec_last_gmm`; replaces the last
 // CconvEcBatch + TileExtractBatch + EntropyBatchGmmTable of EntEncoderFast.forward, test/lic360_demo.py:132-140,
@@ -1073,20 +1116,29 @@ LIC360_API int lic360_cconv16_ec(void *stream, const lic360_conv_plan *p, const 
 // [weight, sigma, mu] (net-major), cout must be 3; the nets' outputs of a tile meet in LDS and never reach HBM; per symbol
 // only (cdf[sym], cdf[sym+1]) is written, at the symbol's place in coding order.  pidx / plane_start: device copies of the
 // CodeContex prefix table and of the first-record-of-plane table.
-LIC360_API int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
-                                        const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
-                                        void *rec, int images, int h, int w, int *ctr) {
+// list / cnt / cap as in lic360_cconv16_ec_list (five groups per block, two tiles per task, N = images).  The records of a skipped (tile, group block) are
+// NOT written -- all its symbols are masked, their records are (0, 0): the caller clears `rec` before a launch with a list.
+int lic360_cconv16_ec_tables_list(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                                  const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
+                                  void *rec, int images, int h, int w, int *ctr, const int *list, const int *cnt, int cap) {
     ARG_CHECK(p && conv16_ok(p) && p->cin == 4 && p->cout == 3 && x && packed16 && bias && code && mask && pidx_dev && plane_start_dev && rec &&
               ctr && images > 0 && h > 0 && w > 0);
+    ARG_CHECK((list != nullptr) == (cnt != nullptr) && (!list || cap > 0));
     C16Args a;
     a.x = x; a.packed = packed16; a.bias = bias; a.act = nullptr; a.residual = nullptr; a.out = nullptr; a.ctr = ctr;
     a.npb = images; a.x_mod = 3 * images; a.N = images;
     if (c16_fill_args(a, p, h, w, C16_FTPT)) return 2;
     a.n_gb = (p->ngroup + C16_FGPB - 1) / C16_FGPB;                         // five groups per block (lic360_conv16_pack_tables)
     a.code = code; a.mask = mask; a.pidx = pidx_dev; a.plane_start = plane_start_dev; a.rec = (uint2 *)rec;
+    a.list = list; a.cnt = cnt; a.list_cap = cap;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(ctr, 0, 8 * sizeof(int), s));
     hipLaunchKernelGGL((k_cconv16<4, true>), dim3(256), dim3(C16_THREADS), 0, s, a);
     LAUNCH_CHECK();
     return 0;
+}
+LIC360_API int lic360_cconv16_ec_tables(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                                        const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
+                                        void *rec, int images, int h, int w, int *ctr) {
+    return lic360_cconv16_ec_tables_list(stream, p, x, packed16, bias, code, mask, pidx_dev, plane_start_dev, rec, images, h, w, ctr, nullptr, nullptr, 0);
 }

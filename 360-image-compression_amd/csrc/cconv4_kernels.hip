@@ -27,6 +27,7 @@
 #include "conv_plan.h"
 
 #include "cconv_tree.h"
+#include "need.h"
 
 #define C4_COLS 68                       // 64 positions + 2*2 halo
 #define C4_WSLOTS 128                    // weight slots per step (>= 25*cin), 4 floats each
@@ -100,6 +101,13 @@ int lic360_cconv4_dc_plane_mode(void *stream, const lic360_conv_plan *p, const f
     if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
     return launch_cconv4v6_dc((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, (mode & 2) != 0,
                               (mode >> 2) & 3);
+}
+int lic360_cconv4_dc_plane_list(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod,
+                                const void *list, const int *cnt, int cap) {
+    ARG_CHECK(p && conv4_ok(p) && x && packed4 && bias && out && n > 0 && nb > 0 && n % nb == 0 && x_mod > 0 && x_mod <= n);
+    if (psum < 0 || psum >= h + w + p->ngroup - 2) return 0;
+    return launch_cconv4v6_dc_list((hipStream_t)stream, p, x, packed4, bias, act, residual, out, n, h, w, nb, psum, x_mod, (const uint4 *)list, cnt, cap);
 }
 // LIC360_NOPACK / LIC360_DC_GSTEP force the schedule variants (both are tested against the oracle); read once per process, not per launch
 int lic360_dc4_env_mode(void) {

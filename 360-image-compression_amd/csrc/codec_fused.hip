@@ -14,6 +14,7 @@
 #include "ac_core.h"
 #include "lic360_exact_math.h"
 #include "gmm_tables.h"
+#include "need.h"
 #include <vector>
 #include <cstring>
 #include <algorithm>
@@ -50,6 +51,16 @@ struct lic360_codec {
     uint4 *d_tab = nullptr;                    // per-plane CDF tables [maxB][tab_pitch][2] (k_dec_tables -> k_dec_plane)
     int tab_pitch = 0;
     bool layer_set[12];
+    // Dead-cone skip (round 6, need.h): outputs no coded symbol can observe are not computed -- per-layer need maps from the mask, compacted task lists
+    // for the encode-order kernels (layers 1..11), per-plane task records for the decode-order kernel (layers 1..11; batches of >= 16 images with
+    // 8 | batch on images of at most 64 rows -- below that a list could only drop whole three-group tasks, which almost never happens, and the decode
+    // would have to wait for the whole importance map instead of running behind it).  LIC360_NOSKIP=1 (read at create) turns it off.
+    bool skip = false;
+    signed char *need = nullptr, *need_d = nullptr, *tmax = nullptr;
+    lic360_ec_lists ecl;
+    lic360_dc_lists dcl;
+    unsigned long long *stats = nullptr;       // [2][12][NEED_STAT_G]: live tiles per (layer, group block) of the encodes, stored cells per (layer, group) of the decodes
+    bool stats_on = false;
     // optional per-kernel-class timing (bench.py's instrumented pass; off in the timed region): HIP event pairs around
     // every launch of a class, recorded on the launch stream
     bool prof = false;
@@ -707,6 +718,27 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     for (int p = 0; p < c->P; ++p) c->tab_pitch = std::max(c->tab_pitch, c->h_plane_start[p + 1] - c->h_plane_start[p]);
     c->tab_pitch = (c->tab_pitch + 63) / 64 * 64;
     rc |= dmalloc(&c->d_tab, 2 * B * (size_t)c->tab_pitch);                 // two uint4 per symbol (dec_pack8)
+    c->skip = c->use4 && !getenv("LIC360_NOSKIP");
+    if (c->skip) {
+        const size_t S = c->S, nt = (size_t)((h + 3) / 4) * ((w + 15) / 16);
+        rc |= dmalloc(&c->need, B * NEED_LAYERS * HW);
+        rc |= dmalloc(&c->need_d, B * NEED_LAYERS * S * h);
+        rc |= dmalloc(&c->tmax, B * NEED_LAYERS * nt);
+        rc |= dmalloc(&c->stats, 2 * NEED_LAYERS * NEED_STAT_G);
+        c->ecl.cap = (int)(((3 * B + 7) / 8) * ((nt + 3) / 4) * ((G + 3) / 4));          // tasks of an XCD's list, hidden layers (the fused layer's is shorter)
+        const size_t cap11 = ((B + 7) / 8) * ((nt + 1) / 2) * ((G + 4) / 5);
+        if ((size_t)c->ecl.cap < cap11) c->ecl.cap = (int)cap11;
+        rc |= dmalloc(&c->ecl.list, (size_t)NEED_LAYERS * 8 * c->ecl.cap);
+        rc |= dmalloc(&c->ecl.cnt, (size_t)NEED_LAYERS * 8);
+        if (h <= 64 && max_batch % 8 == 0 && max_batch >= 16 && max_batch <= 512 && ngroup <= 72) {
+            c->dcl.P = c->P;
+            c->dcl.cap = (int)(((G + 2) / 3) * 3 * (B / 8));
+            rc |= dmalloc(&c->dcl.list, (size_t)NEED_LAYERS * c->P * 8 * c->dcl.cap);
+            rc |= dmalloc(&c->dcl.cnt, (size_t)NEED_LAYERS * c->P * 8);
+        }
+        if (rc) return 1;
+        HIP_TRY(hipMemset(c->stats, 0, 2 * NEED_LAYERS * NEED_STAT_G * sizeof(unsigned long long)));
+    }
     if (rc) return 1;
     // decode activations are only ever read where already written or with a zero weight; they must be finite
     HIP_TRY(hipMemset(c->e_x0, 0, (B * G * EPL + TAIL) * 4));
@@ -726,6 +758,8 @@ LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     (void)hipFree(c->e_x0); for (int i = 0; i < 3; ++i) (void)hipFree(c->e_buf[i]);
     (void)hipFree(c->e_rec); (void)hipFree(c->d_x0); for (int i = 0; i < 11; ++i) (void)hipFree(c->d_act[i]);
     (void)hipFree(c->d_y); (void)hipFree(c->d_state); (void)hipFree(c->d_tab); (void)hipFree(c->e_ctr);
+    (void)hipFree(c->need); (void)hipFree(c->need_d); (void)hipFree(c->tmax); (void)hipFree(c->stats);
+    (void)hipFree(c->ecl.list); (void)hipFree(c->ecl.cnt); (void)hipFree(c->dcl.list); (void)hipFree(c->dcl.cnt);
     for (int i = 0; i < 12; ++i) (void)hipFree(c->packed16[i]);
     for (int k = 0; k < PROF_NCLS; ++k)
         for (hipEvent_t e : c->ev[k]) (void)hipEventDestroy(e);
@@ -772,8 +806,15 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     hipLaunchKernelGGL(k_enc_prep, dim3(lic360_blocks(total, 4)), dim3(256), 0, s, code, mask, c->e_x0, total, H, W, c->e_hp, c->e_wp, c->e_off);
     LAUNCH_CHECK();
     float *cur = c->e_buf[0], *t1 = c->e_buf[1], *nxt = c->e_buf[2];
+    if (c->skip) {                                                      // need maps of this batch's masks, the live tasks of layers 1..11
+        if (lic360_need_build(stream, mask, B, G, H, W, c->need, c->need_d, c->tmax)) return 1;
+        if (lic360_ec_lists_build(stream, c->tmax, B, G, H, W, c->ecl, c->stats_on ? c->stats : nullptr)) return 1;
+    }
     auto ec = [&](int layer, const float *xin, const float *res, float *dst, int x_mod) -> int {
         lic360_conv_plan *p = c->plan[plan_of(layer)];
+        if (c->use4 && c->skip && layer > 0)
+            return lic360_cconv16_ec_list(stream, p, xin, c->packed16[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod, c->e_ctr,
+                                          c->ecl.list + (size_t)layer * 8 * c->ecl.cap, c->ecl.cnt + layer * 8, c->ecl.cap);
         if (c->use4) return lic360_cconv16_ec(stream, p, xin, c->packed16[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod, c->e_ctr);
         return lic360_cconv_ec_ex(stream, p, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, x_mod);
     };
@@ -788,6 +829,12 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     if (rc) return 1;
     if (c->use4) {
         // last layer + CDF tables in one kernel: the nets' outputs never reach HBM (no y buffer, no k_enc_tables)
+        if (c->skip) {
+            // a skipped (tile, group block) holds masked symbols only: their records are (0, 0) and nobody writes them
+            HIP_TRY(hipMemsetAsync(c->e_rec, 0, (size_t)B * G * c->HW * sizeof(uint2), s));
+            PROF(c, PROF_EC_LAST, s, rc |= lic360_cconv16_ec_tables_list(stream, c->plan[2], cur, c->packed16[11], c->bias[11], code, mask, c->d_pidx, c->d_plane_start,
+                                                                         c->e_rec, B, H, W, c->e_ctr, c->ecl.list + (size_t)11 * 8 * c->ecl.cap, c->ecl.cnt + 11 * 8, c->ecl.cap));
+        } else
         PROF(c, PROF_EC_LAST, s, rc |= lic360_cconv16_ec_tables(stream, c->plan[2], cur, c->packed16[11], c->bias[11], code, mask, c->d_pidx,
                                                                 c->d_plane_start, c->e_rec, B, H, W, c->e_ctr));
         if (rc) return 1;
@@ -814,8 +861,20 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
     hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
     LAUNCH_CHECK();
     const int *pih = c->h_pidx.data();
+    // dead-cone skip: the whole mask must be final before the first plane (a gated decode waits for the map's LAST event instead of plane by plane)
+    const bool lists = c->skip && c->dcl.list && B % 8 == 0 && B >= 16;
+    if (lists) {
+        if (gate) { HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)gate[n_gate - 1], 0)); gate = nullptr; }
+        if (lic360_need_build(stream, mask, B, G, H, W, c->need, c->need_d, c->tmax)) return 1;
+        if (lic360_dc_lists_build(stream, c->need_d, B, G, H, W, c->dcl, c->stats_on ? c->stats + NEED_LAYERS * NEED_STAT_G : nullptr)) return 1;
+    }
     auto dc = [&](int layer, const float *xin, const float *res, float *dst, int x_mod, int p) -> int {
         lic360_conv_plan *pl = c->plan[plan_of(layer)];
+        if (lists && layer > 0) {
+            const size_t li = ((size_t)layer * c->P + p) * 8;
+            return lic360_cconv4_dc_plane_list(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod,
+                                               c->dcl.list + li * c->dcl.cap, c->dcl.cnt + li, c->dcl.cap);
+        }
         if (c->use4) return lic360_cconv4_dc_plane_mode(stream, pl, xin, c->packed4[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3, p, x_mod, c->dc_mode);
         return lic360_cconv_dc_plane_ex(stream, pl, xin, c->packed[layer], c->bias[layer], c->act[layer], res, dst, 3 * B, H, W, 3,
                                         c->d_idx, c->d_pidx, pih, p, x_mod, 1);
@@ -1476,5 +1535,70 @@ LIC360_API int lic360_codec_profile_read(lic360_codec *c, int n, double *ms, lon
         launches[k] = (long)(cnt / 2);
         c->n_ev[k] = 0;
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ dead-cone skip: statistics and test hooks
+// enable > 0: the following encodes / decodes count what they execute (0: stop, < 0: unchanged); out (host, 2 * 12 * 64 values, may be NULL): [0][layer][group block] live
+// (tile, group block) pairs of the encode-order launches -- 64 positions x the block's groups each, per sample --, [1][layer][group] cells the
+// decode-order launches stored; reading clears the counters.  skip_active_out (may be NULL): 1 if this codec skips at all (0: generic kernels or LIC360_NOSKIP).
+LIC360_API int lic360_codec_skip_stats(lic360_codec *c, int enable, unsigned long long *out, int *skip_active_out) {
+    ARG_CHECK(c);
+    if (skip_active_out) *skip_active_out = c->skip ? 1 + (c->dcl.list ? 1 : 0) : 0;
+    if (!c->skip) { if (out) memset(out, 0, 2 * NEED_LAYERS * NEED_STAT_G * sizeof(unsigned long long)); return 0; }
+    if (enable >= 0) c->stats_on = enable != 0;                        // (< 0: leave the switch alone)
+    if (out) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, c->stats, 2 * NEED_LAYERS * NEED_STAT_G * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(c->stats, 0, 2 * NEED_LAYERS * NEED_STAT_G * sizeof(unsigned long long)));
+    }
+    return 0;
+}
+// Test hook: every interior cell of every activation buffer of the codec (encode-order ping-pong buffers, decode-order layer buffers and y) <- value;
+// halo / padding cells stay zero.  A following encode / decode must produce the same bytes / symbols whatever the value: live cells are written
+// before they are read, dead cells are only read with zero weights or by dead chains (tests/test_gpu_need.py; finite values only: 0 * NaN is NaN).
+__global__ void k_fill_enc(float *buf, long planes, int H, int W, int hp, int wp, int off, float v) {
+    GRID_STRIDE(i, planes * H * W) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        buf[(i / ((long)H * W)) * hp * wp + e_cell(y, x, wp, off)] = v;
+    }
+}
+__global__ void k_fill_dec(float *buf, long planes, int H, int W, int sk_rows, int sk_pitch, int row0, int col0, float v) {
+    GRID_STRIDE(i, planes * H * W) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        buf[(i / ((long)H * W)) * sk_rows * sk_pitch + (long)(y + x + row0) * sk_pitch + y + col0] = v;
+    }
+}
+LIC360_API int lic360_codec_debug_fill(void *stream, lic360_codec *c, float value) {
+    ARG_CHECK(c && value == value && value - value == 0.0f);
+    hipStream_t s = (hipStream_t)stream;
+    const long B = c->maxB, G = c->G;
+    for (int i = 0; i < 3; ++i) {
+        hipLaunchKernelGGL(k_fill_enc, dim3(lic360_blocks(3 * B * 4 * G * c->HW, 4)), dim3(256), 0, s, c->e_buf[i], 3 * B * 4 * G, c->H, c->W, c->e_hp, c->e_wp, c->e_off, value);
+        LAUNCH_CHECK();
+    }
+    for (int i = 0; i < 11; ++i) {
+        hipLaunchKernelGGL(k_fill_dec, dim3(lic360_blocks(3 * B * 4 * G * c->HW, 4)), dim3(256), 0, s, c->d_act[i], 3 * B * 4 * G, c->H, c->W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0, value);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_fill_dec, dim3(lic360_blocks(3 * B * 3 * G * c->HW, 4)), dim3(256), 0, s, c->d_y, 3 * B * 3 * G, c->H, c->W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0, value);
+    LAUNCH_CHECK();
+    return 0;
+}
+// Test hook: what the last encode / decode of the codec scheduled, copied to the host.  which 0: need maps [maxB][12][H][W] int8; 1: encode list counts
+// [12][8] int; 2: encode lists [12][8][cap] int; 3: decode list counts [12][P][8] int; 4: decode records [12][P][8][cap] x 4 unsigned.  *cap_out: cap.
+LIC360_API int lic360_codec_debug_lists(lic360_codec *c, int which, void *host_out, long bytes, int *cap_out) {
+    ARG_CHECK(c && host_out && bytes >= 0 && which >= 0 && which <= 4 && c->skip);
+    HIP_TRY(hipDeviceSynchronize());
+    const void *src = nullptr;
+    long have = 0;
+    if (which == 0) { src = c->need; have = (long)c->maxB * NEED_LAYERS * c->HW; }
+    else if (which == 1) { src = c->ecl.cnt; have = NEED_LAYERS * 8 * 4L; }
+    else if (which == 2) { src = c->ecl.list; have = (long)NEED_LAYERS * 8 * c->ecl.cap * 4; }
+    else if (which == 3) { src = c->dcl.cnt; have = c->dcl.list ? (long)NEED_LAYERS * c->P * 8 * 4 : 0; }
+    else { src = c->dcl.list; have = c->dcl.list ? (long)NEED_LAYERS * c->P * 8 * c->dcl.cap * 16 : 0; }
+    if (cap_out) *cap_out = which <= 2 ? c->ecl.cap : c->dcl.cap;
+    ARG_CHECK(src && bytes <= have);
+    HIP_TRY(hipMemcpy(host_out, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }

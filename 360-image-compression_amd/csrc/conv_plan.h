@@ -27,3 +27,14 @@ int lic360_cconv_dc_plane_strided(void *stream, const lic360_conv_plan *p, const
                                   const float *act, const float *residual, float *out, int n, int h, int w, int nb,
                                   const int *idx_dev, const int *plane_idx_dev, const int *plane_idx_host, int psum, int x_mod,
                                   long x_cs, long x_hs, long x_ws, long o_cs, long o_hs, long o_ws);
+// the dead-cone skip's entries (round 6; need.h): the encode-order kernels over a compacted list of live tasks, the decode-order kernel over the
+// (layer, plane)'s task records
+int lic360_cconv16_ec_list(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                           const float *act, const float *residual, float *out, int n, int h, int w, int nb, int x_mod, int *ctr,
+                           const int *list, const int *cnt, int cap);
+int lic360_cconv16_ec_tables_list(void *stream, const lic360_conv_plan *p, const float *x, const float *packed16, const float *bias,
+                                  const float *code, const float *mask, const int *pidx_dev, const int *plane_start_dev,
+                                  void *rec, int images, int h, int w, int *ctr, const int *list, const int *cnt, int cap);
+int lic360_cconv4_dc_plane_list(void *stream, const lic360_conv_plan *p, const float *x, const float *packed4, const float *bias,
+                                const float *act, const float *residual, float *out, int n, int h, int w, int nb, int psum, int x_mod,
+                                const void *list, const int *cnt, int cap);

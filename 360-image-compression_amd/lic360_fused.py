@@ -121,6 +121,37 @@ class FusedCodec(object):
             raise Lic360Error("arithmetic decoder fault (corrupt stream?): %s" % self.err[:b].cpu().tolist())
         return out
 
+    # ---- dead-cone skip (csrc/need.h): statistics and test hooks ---------------------------------------
+    def skip_active(self):
+        """0: this codec computes every output (generic kernels or LIC360_NOSKIP); 1: the encode-order launches skip dead (tile, group block)
+        pairs; 2: the decode-order launches of batches of >= 16 images (8 | batch) skip dead rows as well"""
+        act = C.c_int(0)
+        _chk(_lib.lic360_codec_skip_stats(self._h, -1, None, C.byref(act)))
+        return act.value
+
+    def skip_stats(self, enable=True, read=False):
+        """enable: count what the following encodes / decodes execute.  read: -> (enc [12, 64] live (tile, group block) pairs per (layer,
+        group block), dec [12, 64] stored cells per (layer, group)) since the last read, as numpy uint64 arrays; reading clears."""
+        import numpy as np
+        out = np.zeros((2, 12, 64), np.uint64) if read else None
+        _chk(_lib.lic360_codec_skip_stats(self._h, int(bool(enable)), out.ctypes.data_as(C.c_void_p) if read else None, None))
+        return (out[0], out[1]) if read else None
+
+    def debug_fill(self, value):
+        _chk(_lib.lic360_codec_debug_fill(_stream(self.device), self._h, C.c_float(float(value))))
+
+    def debug_lists(self, which):
+        """what the last encode / decode scheduled (which: see lic360_codec_debug_lists) as a flat numpy array + the list capacity"""
+        import numpy as np
+        P = self.H + self.W + self.G - 2
+        cap = C.c_int(0)
+        probe = np.zeros(1, np.int8)
+        _chk(_lib.lic360_codec_debug_lists(self._h, int(which), probe.ctypes.data_as(C.c_void_p), C.c_long(0), C.byref(cap)))
+        n = {0: self.maxB * 12 * self.H * self.W, 1: 12 * 8 * 4, 2: 12 * 8 * cap.value * 4, 3: 12 * P * 8 * 4, 4: 12 * P * 8 * cap.value * 16}[int(which)]
+        buf = np.zeros(n, np.int8)
+        _chk(_lib.lic360_codec_debug_lists(self._h, int(which), buf.ctypes.data_as(C.c_void_p), C.c_long(n), None))
+        return (buf if which == 0 else buf.view(np.uint32 if which == 4 else np.int32)), cap.value
+
     # ---- timing hooks (bench.py) ---------------------------------------------------------------------
     def profile(self, on=True):
         _chk(_lib.lic360_codec_profile_enable(self._h, int(on)))

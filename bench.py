@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
                     "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
     ap.add_argument("--imp-streams", type=int, default=1, help="1: the importance-map codecs run on HIP streams of their own; 0: on their sub-batch's stream")
+    ap.add_argument("--masks", choices=("smooth", "iid"), default="smooth", help="importance maps of the synthetic latents: smooth = SURVEY.md 8d's "
+                    "L = clip(round(24 + 12 cos(lat) n)), n smooth noise (tests/util.py:latent_smooth; the workload since round 6); iid = every map cell drawn "
+                    "independently (rounds 1-5; the adversarial case of the dead-cone skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip latent-only pass, single image, config4, streaming ops)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch / sharding / reporting path on gloo: no codec work, value 0")
@@ -87,12 +90,15 @@ def split_for_streams(n, ns):
     return sizes
 
 
-def synth_latents(batch, seed0, h=H, w=W):
+MASKS = "smooth"
+
+
+def synth_latents(batch, seed0, h=H, w=W, kind=None):
     import numpy as np
-    from util import latent
+    from util import make_latent
     codes, masks, levels = [], [], []
     for i in range(batch):
-        c, m, lv = latent(np.random.default_rng(seed0 + i), G, h, w)
+        c, m, lv = make_latent(kind or MASKS, np.random.default_rng(seed0 + i), G, h, w)
         codes.append(c)
         masks.append(m)
         levels.append(lv)
@@ -215,6 +221,8 @@ def dry_run(args):
 
 
 def run_rank(args):
+    global MASKS
+    MASKS = args.masks
     # numpy's / torch's host pools; the oracle's own pool is set per leg by cpu_baseline (orc_set_num_threads: all host cores, then 16)
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, host_cpu()[0])))
     import numpy as np

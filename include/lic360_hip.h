@@ -361,6 +361,22 @@ int lic360_devcoder_encode(void *stream, const int *tables, int ncode, const int
 int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const float *mask, long n, int chunk,
                            const uint8_t *bytes, long cap, const int *nbytes, float *out, int *err);
 
+/* ---- dead-cone skip of the fused latent codec (round 6; csrc/need.h) -------------------------------------------------------------
+ * The reference evaluates every output of the entropy nets (extension/cconv_ec_cuda.cu:317-339, cconv_dc_cuda.cu:367-398) and coder.cpp:79 then
+ * skips the masked symbols.  The fused codec does not compute what no coded symbol can observe: need_l(y, x) = highest group of layer l whose
+ * output some coded symbol reads (-1: none), need_11 = the mask's highest coded group, need_l = min(G - 1, 5 x 5 dilation of need_{l+1} + dy + dx).
+ * Bitstreams and decoded symbols are unchanged.  lic360_need_maps: masks [b, g, h, w] -> need [b][12][h][w] int8 (device), the kernel the codec runs. */
+int lic360_need_maps(void *stream, const float *mask, int b, int g, int h, int w, signed char *need_out);
+/* enable > 0: the following encodes / decodes count what they execute (0: stop; < 0: leave as it is).  out (host, 2 * 12 * 64 values, may be NULL; reading clears):
+ * [0][layer][group block] live (tile, group block) pairs of the encode-order launches (64 positions x the block's groups, per sample),
+ * [1][layer][group] cells the decode-order launches stored.  *skip_active_out (may be NULL): 0 the codec does not skip (generic kernels or
+ * LIC360_NOSKIP), 1 encode order only, 2 both orders (decode order: batches of >= 16 images, 8 | batch, h <= 64). */
+int lic360_codec_skip_stats(lic360_codec *codec, int enable, unsigned long long *out, int *skip_active_out);
+/* test hooks: every interior cell of the codec's activation buffers <- value (finite); what the last encode / decode scheduled
+ * (which 0: need maps, 1 / 2: encode-order list counts / entries, 3 / 4: decode-order list counts / records; see csrc/codec_fused.hip) */
+int lic360_codec_debug_fill(void *stream, lic360_codec *codec, float value);
+int lic360_codec_debug_lists(lic360_codec *codec, int which, void *host_out, long bytes, int *cap_out);
+
 /* timing hooks for bench.py's instrumented pass: HIP events around every launch of each kernel class of the codec
  * (classes() names them, comma separated: first / hidden / last conv layers in both orders, table builds, coder kernels),
  * recorded on the caller's stream; read() fills ms[k] / launches[k] per class (n >= number of classes) and resets */

@@ -7,6 +7,7 @@ without spending minutes of oracle time on the GPU box.
   cfg3  one 512x1024 ERP latent,              model-idx 3 --ssim   (weights seed 1003)   configs[2]: decode
   cfg5  one 1024x2048 ERP latent (48x128x256), model-idx 7 --ssim  (weights seed 1007)   configs[4]
   cfg2b / cfg3b  a second image of cfg2 / cfg3 at a dense (85 %) / sparse (15 %) mask
+  cfg2s / cfg3s / cfg5s  the same configurations on SURVEY.md 8d's smooth importance maps (round 6)
 
 Per case the file holds DATA only: the latent seed, the oracle's latent bitstream and importance-map bitstream (raw
 bytes) and their SHA-256.  Weights and latents are regenerated from the seeds by tests/util.py (numpy Generator streams
@@ -28,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count() or 1))
 
 import ref_codec as rc  # noqa: E402
-from util import latent, make_main_params, make_imp_params  # noqa: E402
+from util import make_latent, make_main_params, make_imp_params  # noqa: E402
 
 G = 48
 CASES = {
@@ -39,6 +40,11 @@ CASES = {
     # and sparse (15 %) importance maps instead of the default 50 %
     "cfg2b": dict(H=64, W=128, model_idx=0, ssim=0, latent_seed=2001, mean=0.85, spread=0.10),
     "cfg3b": dict(H=64, W=128, model_idx=3, ssim=1, latent_seed=3001, mean=0.15, spread=0.10),
+    # round 6: the same three configurations on SURVEY.md 8d's importance maps (smooth noise x cos(latitude), tests/util.py:latent_smooth) -- the
+    # workload the bench times since round 6; the five cases above (every map cell drawn independently) stay as the adversarial family
+    "cfg2s": dict(H=64, W=128, model_idx=0, ssim=0, latent_seed=2000, kind="smooth"),
+    "cfg3s": dict(H=64, W=128, model_idx=3, ssim=1, latent_seed=3000, kind="smooth"),
+    "cfg5s": dict(H=128, W=256, model_idx=7, ssim=1, latent_seed=5000, kind="smooth"),
 }
 
 
@@ -50,7 +56,7 @@ def main():
         wseed = 1000 * c["ssim"] + c["model_idx"]
         layers = make_main_params(wseed, G)
         imp_layers = make_imp_params(wseed)
-        code, mask, levels = latent(np.random.default_rng(c["latent_seed"]), G, c["H"], c["W"], c.get("mean", 0.5), c.get("spread", 0.25))
+        code, mask, levels = make_latent(c.get("kind", "iid"), np.random.default_rng(c["latent_seed"]), G, c["H"], c["W"], c.get("mean", 0.5), c.get("spread", 0.25))
         t0 = time.time()
         data = rc.encode_main(code, mask, layers, G)
         t1 = time.time()
@@ -59,6 +65,7 @@ def main():
         print("%s: latent %d bytes (%.1f s), importance %d bytes (%.1f s)" % (name, len(data), t1 - t0, len(imp), t2 - t1), flush=True)
         np.savez(os.path.join(out_dir, "full_%s.npz" % name),
                  H=c["H"], W=c["W"], G=G, weight_seed=wseed, latent_seed=c["latent_seed"], mean=c.get("mean", 0.5), spread=c.get("spread", 0.25),
+                 kind=c.get("kind", "iid"),
                  bytes=np.frombuffer(data, np.uint8), sha256=hashlib.sha256(data).hexdigest(),
                  imp_bytes=np.frombuffer(imp, np.uint8), imp_sha256=hashlib.sha256(imp).hexdigest(),
                  code_sha256=hashlib.sha256(np.ascontiguousarray(code).tobytes()).hexdigest(),

@@ -6,6 +6,8 @@ build container (tests/golden/full_*.npz, oracle/gen_golden_full.py; 27 s / 109 
   cfg5  configs[4]  1024x2048 ERP (48x128x256 latent), model-idx 7 --ssim -> both directions
   cfg4  configs[3]  is the batch form of cfg3: test_batch_of_cfg3_images checks 8 images per call (one GPU's share)
   cfg2b / cfg3b  a second oracle-pinned image of cfg2 / cfg3 at a dense / sparse importance mask (both directions for cfg3b via the batch test)
+  cfg2s / cfg3s / cfg5s  the same configurations on SURVEY.md 8d's smooth importance maps (round 6: the masks the bench times; the i.i.d. cases
+                 above stay as the adversarial family -- the dead-cone skip finds next to nothing in them)
 """
 import hashlib
 import os
@@ -14,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import latent, make_main_params, make_imp_params
+from util import latent, make_latent, make_main_params, make_imp_params
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -28,7 +30,8 @@ def load(name):
     g = np.load(os.path.join(GOLD, "full_%s.npz" % name))
     G, H, W = int(g["G"]), int(g["H"]), int(g["W"])
     dens = (float(g["mean"]), float(g["spread"])) if "mean" in g.files else (0.5, 0.25)
-    code, mask, levels = latent(np.random.default_rng(int(g["latent_seed"])), G, H, W, *dens)
+    kind = str(g["kind"]) if "kind" in g.files else "iid"
+    code, mask, levels = make_latent(kind, np.random.default_rng(int(g["latent_seed"])), G, H, W, *dens)
     # the fixtures hold digests of the inputs they were made from: a drifting generator fails here, not as a byte mismatch
     assert hashlib.sha256(code.tobytes()).hexdigest() == str(g["code_sha256"])
     assert hashlib.sha256(mask.tobytes()).hexdigest() == str(g["mask_sha256"])
@@ -46,7 +49,7 @@ def codecs(shape, layers, imp_layers, batch=1):
     return fc, ic
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg2b", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg2b", "cfg5", "cfg2s", "cfg5s"])
 def test_full_size_encode_bytes_equal_oracle(name):
     g, shape, code, mask, levels, layers, imp_layers = load(name)
     fc, ic = codecs(shape, layers, imp_layers)
@@ -57,7 +60,7 @@ def test_full_size_encode_bytes_equal_oracle(name):
     assert imp == g["imp_bytes"].tobytes() and hashlib.sha256(imp).hexdigest() == str(g["imp_sha256"])
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg3b", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg3", "cfg3b", "cfg5", "cfg3s", "cfg5s"])
 def test_full_size_decode_of_oracle_bytes(name):
     g, shape, code, mask, levels, layers, imp_layers = load(name)
     fc, ic = codecs(shape, layers, imp_layers)

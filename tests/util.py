@@ -37,6 +37,40 @@ def latent(rng, G, H, W, mean=0.5, spread=0.25):
     return code, mask, L.astype(np.float32)[None, None]
 
 
+def smooth_field(rng, h, w, sigma=3.0):
+    """unit-variance smooth noise on an [h, w] importance map ("n smooth noise"): white N(0,1) noise convolved with a separable
+    Gaussian of `sigma` map cells (radius 3 sigma; longitude wraps around, latitude reflects at the poles), divided by the kernel's L2 norm.
+    Plain numpy sums in a fixed order: the same values on every numpy / scipy version."""
+    r = int(np.ceil(3 * sigma))
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= np.sqrt((k ** 2).sum())
+    z = rng.standard_normal((h, w))
+    zp = np.concatenate([z[r - 1::-1] if r <= h else np.resize(z[::-1], (r, w)), z, z[:-r - 1:-1] if r <= h else np.resize(z[::-1], (r, w))], 0)   # reflect
+    y = sum(k[i] * zp[i:i + h] for i in range(2 * r + 1))
+    cols = (np.arange(-r, w + r) % w)
+    yp = np.ascontiguousarray(y[:, cols])                                                                                                       # wrap
+    return np.ascontiguousarray(sum(k[i] * yp[:, i:i + w] for i in range(2 * r + 1)))
+
+
+def latent_smooth(rng, G, H, W, sigma=3.0):
+    """SURVEY.md 8d's latent-level workload: code in {0..7} ~ round(N(3.5, 1.2^2)); importance level of map cell (r, c)
+    L = clip(round(G/2 + G/4 cos(lat_r) n[r, c]), 0, G) with n = smooth_field (sigma map cells) and lat_r the latitude of map row r
+    (-pi/2 .. pi/2 over the H/2 rows): real importance maps are smooth and flatten towards the poles; mask[g, y, x] = g < L[y/2, x/2]."""
+    code = np.clip(np.rint(rng.normal(3.5, 1.2, (1, G, H, W))), 0, 7).astype(np.float32)
+    h, w = H // 2, W // 2
+    lat = (np.arange(h) + 0.5) / h * np.pi - np.pi / 2
+    L = np.clip(np.rint(G / 2 + G / 4 * np.cos(lat)[:, None] * smooth_field(rng, h, w, sigma)), 0, G).astype(np.int64)
+    Lup = np.repeat(np.repeat(L, 2, 0), 2, 1)
+    mask = (np.arange(G)[:, None, None] < Lup[None]).astype(np.float32)[None]
+    return code, mask, L.astype(np.float32)[None, None]
+
+
+def make_latent(kind, rng, G, H, W, mean=0.5, spread=0.25):
+    """kind "smooth": SURVEY.md 8d's importance maps (latent_smooth); "iid": every map cell drawn independently (latent) -- no real map looks
+    like that; it is kept as the adversarial case (nothing for the dead-cone skip to find) and for the digests committed before round 6"""
+    return latent_smooth(rng, G, H, W) if kind == "smooth" else latent(rng, G, H, W, mean, spread)
+
+
 # ---- synthetic, seeded parameters of the two entropy models (no oracle involved: bench.py uses these too)
 def make_main_params(seed, G):
     """12 layers x 3 stacked nets [weight, sigma, mu] (lic360_demo.py:104-112,302)."""
