@@ -1602,3 +1602,13 @@ LIC360_API int lic360_codec_debug_lists(lic360_codec *c, int which, void *host_o
     HIP_TRY(hipMemcpy(host_out, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+
+// the kernels the fused codecs run per bench kernel class (names as rocprofv3 prints them, templates included): bench.py attaches a committed PMC entry
+// to a row only if every kernel that entry names is listed here for the row's class (tests/test_abi.py checks each base name against the library's symbols)
+LIC360_API const char *lic360_codec_kernel_names(void) {
+    return "ec_first=k_cconv16<1, false>;ec_hidden=k_cconv16s+k_cconv16<4, false>;ec_last=k_cconv16<4, true>;"
+           "dc_first=k_cconv4v6<1, false, false>+k_cconv4v6t<1>;"
+           "dc_hidden=k_cconv4v6l<4>+k_cconv4v6t<4>+k_cconv4v6<4, false, false>+k_cconv4v6<4, false, true>;"
+           "dc_last=k_cconv4v6l<4>+k_cconv4v6t<4>+k_cconv4v6<4, false, false>+k_cconv4v6<4, false, true>;"
+           "imp_ec=k_cconv144<1, false, 2>;imp_dc=k_cconv144<1, true, 2>";
+}

@@ -191,6 +191,12 @@ LIC360_API int lic360_sphere_pad_inplace(void *stream, float *x, int nc, int hp,
     LAUNCH_CHECK();
     return 0;
 }
+// SphereTrim immediately followed by the in-place SpherePad of the same width (test/model_zoo.py:83-84, 90-91, 160-161: `y = self.trim(y); y = self.pad2(y)`):
+// the refresh writes EVERY apron cell the trim zeroed (k_sphere_pad_inplace* enumerate the whole apron), from interior cells the trim does not touch -- the
+// pair is the refresh alone, one pass over the apron's sectors instead of two (147 + 51 -> 147 us per 32 maps of 192 x 260 x 516).
+LIC360_API int lic360_sphere_trim_pad_inplace(void *stream, float *x, int nc, int hp, int wp, int pad) {
+    return lic360_sphere_pad_inplace(stream, x, nc, hp, wp, pad);
+}
 // the apron of dst <- the sphere-wrapped interior of src (same geometry; src == dst is lic360_sphere_pad_inplace): what `x + SphereTrim(y)`
 // leaves in the apron of a block's output when x's apron had been refreshed (test/model_zoo.py:56-62) -- used behind lic360_sconv3x3
 __global__ __launch_bounds__(256) void k_sphere_apron_from_plane(const float *__restrict__ src, float *__restrict__ dst, int per_plane, int Hp, int Wp, int pad) {

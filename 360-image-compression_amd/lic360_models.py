@@ -25,10 +25,11 @@ FUSED_MIN_WORKGROUPS = 256          # lic360.sconv3x3 is used when its workgroup
 FUSED_MIN_FILL = 0.8
 
 
-def _fusable(conv, x, ring, ring_w=None):
-    """does this 3x3 stride-1 convolution of a map with x's batch, height and width run on lic360.sconv3x3?  (inference only: the kernel has
-    no backward)"""
-    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+def _fusable(conv, x, ring, ring_w=None, mod=None):
+    """does this 3x3 stride-1 convolution of a map with x's batch, height and width run on lic360.sconv3x3?  (inference only: the kernels have
+    no backward -- with gradients enabled the fused path is taken only if neither x nor ANY parameter of the block `mod` that the path pushes
+    through them (the 1x1 layers, shortcuts, PReLU slopes, biases: all of the block) requires one)"""
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or (mod is not None and any(p.requires_grad for p in mod.parameters()))):
         return False
     if not (x.is_cuda and x.dtype == torch.float32 and conv.bias is not None):
         return False
@@ -51,13 +52,12 @@ def _packed(conv):
     return conv._s3_packed
 
 
-def _scratch(mod, name, shape, like):
-    """a zero-initialised work buffer owned by the module (cells the kernels never write stay zero); never handed to the caller"""
-    buf = getattr(mod, name, None)
-    if buf is None or tuple(buf.shape) != tuple(shape) or buf.device != like.device:
-        buf = torch.zeros(shape, dtype=torch.float32, device=like.device)
-        setattr(mod, name, buf)
-    return buf
+def _scratch(shape, like):
+    """an intermediate of a fused block: a fresh buffer per call from the caching allocator (which tracks the stream it is used on), so one model may
+    run on several HIP streams at once (module-owned buffers raced there).  Its apron is NOT initialised and need not be: every consumer
+    reads aprons by index from the interior (sconv3x3 with sphere != 0), refreshes them in place (SpherePad), works position by position and is trimmed
+    afterwards (1x1 layers, PReLU, GDN), or overwrites them (SphereTrim, sphere_apron_from)."""
+    return torch.empty(tuple(shape), dtype=torch.float32, device=like.device)
 
 
 class ResidualBlock(nn.Module):
@@ -72,18 +72,18 @@ class ResidualBlock(nn.Module):
         self.trim = SphereTrim(2, device_id)
 
     def forward(self, x):
-        if _fusable(self.conv2, x, 2) and x.is_contiguous():
+        if _fusable(self.conv2, x, 2, mod=self) and x.is_contiguous():
             # conv1 and PReLU are pointwise, so the apron of relu1(conv1(pad(x))) is the sphere wrap of its own interior: conv2 reads it
             # by index and x needs no refresh; only the interior of conv2's output survives the final trim.  The 1x1 layers run on the same
             # kernel body with their PReLU / residual add in the epilogue (interior window only) when their shapes allow it.
             n, c, hp, wp = x.shape
             one = lic360.sconv1x1_supported(c, c // 2) and lic360.sconv1x1_supported(c // 2, c) and self.conv1.bias is not None and self.conv3.bias is not None
             if one:
-                y = _scratch(self, "_s3_y", (n, c // 2, hp, wp), x)
+                y = _scratch((n, c // 2, hp, wp), x)
                 lic360.sconv1x1(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, y, ring=2)
             else:
                 y = self.relu1(self.conv1(x)).contiguous()
-            y2 = _scratch(self, "_s3_y2", y.shape, y)
+            y2 = _scratch(y.shape, y)
             lic360.sconv3x3(y, _packed(self.conv2), self.conv2.bias, self.relu2.weight, None, y2, pad=2, sphere=True, ring=2)
             if one:
                 out = torch.empty_like(x)
@@ -104,7 +104,7 @@ class AttentionBlock(nn.Module):
         self.attention = nn.Sequential(*three(), _conv(channels, channels, 1), nn.Sigmoid())
 
     def forward(self, x):
-        if _fusable(self.trunk[0].conv2, x, 2):
+        if _fusable(self.trunk[0].conv2, x, 2, mod=self.trunk[0]):
             x = self.trunk[0].pad(x)                                       # the reference's first ResidualBlock refreshes x's apron in place: `x + ...` below carries it
         return x + self.trunk(x) * self.attention(x)
 
@@ -118,12 +118,12 @@ class ResidualBlockV2(nn.Module):
         self.conv2, self.relu2, self.trim2 = _conv(channels, channels, 3, 1, 1), nn.PReLU(channels), SphereTrim(2, device_id)
 
     def forward(self, x):
-        if _fusable(self.conv1, x, 1, 2) and x.is_contiguous():
+        if _fusable(self.conv1, x, 1, 2, mod=self) and x.is_contiguous():
             # conv1 over the apron read by index, output on the rows of the 1-ring window (the outermost ring is never read) and on the
             # interior's columns only: its input is periodic in longitude, so its 1-ring COLUMNS would repeat its interior's last / first
             # column bit for bit -- conv2 reads them there (longitude wrap), reads the rows as they are, adds x on the interior; the
             # output's apron is x's refreshed apron, as `x + trim2(...)` leaves it in the reference
-            y1 = _scratch(self, "_s3_y1", x.shape, x)
+            y1 = _scratch(x.shape, x)
             lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, y1, pad=2, sphere=1, ring=1, ring_w=2)
             out = torch.empty_like(x)
             lic360.sconv3x3(y1, _packed(self.conv2), self.conv2.bias, self.relu2.weight, x, out, pad=2, sphere=2, ring=2)
@@ -152,10 +152,14 @@ class ResidualBlockDown(nn.Module):
         else:
             x = self.pad1(x)
             skip, y = None, x
-        y = self.trim(self.relu1(self.conv1(y)))
-        if _fusable(self.conv2, y, 2) and y.is_contiguous():
+        # (the reference trims here and refreshes the same apron at once -- `trim` then `pad2` in place, model_zoo.py:83-84,90-91: the refresh
+        #  overwrites every cell the trim zeroed, and the fused conv2 does not read the apron at all: one launch less on either path, same result)
+        y = self.relu1(self.conv1(y))
+        if torch.is_grad_enabled() and y.requires_grad:
+            y = self.trim(y)                                                # a recording pass keeps the reference's sequence: the in-place pad's backward leaves the apron's gradient for the trim's to zero
+        if _fusable(self.conv2, y, 2, mod=self) and y.is_contiguous():
             # conv2 reads the apron of y by index (no pad2); GDN is pointwise over positions, its frame cells are trimmed below
-            y2 = _scratch(self, "_s3_y2", y.shape, y)
+            y2 = _scratch(y.shape, y)
             y = self.relu2(lic360.sconv3x3(y, _packed(self.conv2), self.conv2.bias, None, None, y2, pad=2, sphere=True, ring=2))
         else:
             y = self.relu2(self.conv2(self.pad2(y)))
@@ -212,7 +216,7 @@ class ResidualBlockUp(nn.Module):
         self.cut_edge, self.dtow2, self.trim2 = SphereCutEdge(1, d), Dtow(2, True, d), SphereTrim(2, d)
 
     def forward(self, x):
-        if _fusable(self.conv1, x, 2) and x.is_contiguous():
+        if _fusable(self.conv1, x, 2, mod=self) and x.is_contiguous():
             # the unpadded conv1 (output (h+2) x (w+2)) with PReLU in its epilogue, on the INTERIOR's window only: its 1-ring outputs become the
             # 2-ring of the shuffled map, which trim1 zeroes; x's apron is read by index (no pad1), and the shortcut's apron cells end in the
             # rings trim2 zeroes
@@ -220,17 +224,19 @@ class ResidualBlockUp(nn.Module):
             # map): conv1 -> PReLU -> Dtow -> trim1 in one launch.  The window lands exactly on the shuffled map's interior; its apron is
             # never read (conv2 reads aprons by index, or pad2 refreshes it), so trim1 has nothing to do.
             n, c, hp, wp = x.shape
-            b = _scratch(self, "_s3_b", (n, self.conv1.out_channels // 4, 2 * (hp - 2), 2 * (wp - 2)), x)
+            b = _scratch((n, self.conv1.out_channels // 4, 2 * (hp - 2), 2 * (wp - 2)), x)
             lic360.sconv3x3(x, _packed(self.conv1), self.conv1.bias, self.relu1.weight, None, b, pad=2, sphere=1, ring=2, crop=1, shuffle=True)
         else:
-            b = self.trim1(self.dtow1(self.relu1(self.conv1(self.pad1(x)))))
-        if _fusable(self.conv2, b, 2) and b.is_contiguous():
-            b2 = _scratch(self, "_s3_b2", b.shape, b)
+            b = self.dtow1(self.relu1(self.conv1(self.pad1(x))))           # (trim1 -> pad2 in place, model_zoo.py:160-161: the refresh overwrites what the trim zeroed)
+            if torch.is_grad_enabled() and b.requires_grad:
+                b = self.trim1(b)                                           # (recording pass: the reference's sequence, see ResidualBlockDown)
+        if _fusable(self.conv2, b, 2, mod=self) and b.is_contiguous():
+            b2 = _scratch(b.shape, b)
             b = self.relu2(lic360.sconv3x3(b, _packed(self.conv2), self.conv2.bias, None, None, b2, pad=2, sphere=True, ring=2))
         else:
             b = self.relu2(self.conv2(self.pad2(b)))
         c_in, c_out = self.short_cut.in_channels, self.short_cut.out_channels
-        if (_fusable(self.conv2, b, 2) and x.is_contiguous() and b.is_contiguous() and lic360.sconv1x1_supported(c_in, c_out) and self.short_cut.bias is not None
+        if (_fusable(self.conv2, b, 2, mod=self) and x.is_contiguous() and b.is_contiguous() and lic360.sconv1x1_supported(c_in, c_out) and self.short_cut.bias is not None
                 and tuple(b.shape) == (x.shape[0], c_out // 4, 2 * (x.shape[2] - 2), 2 * (x.shape[3] - 2))):
             # the shortcut -- cut_edge(1) -> 1x1 conv to 4c -> Dtow(2) -- and the `b +` in one launch: the 1x1 instantiation with the shuffled store,
             # b as its (shuffled) residual, on the interior window (trim2 zeroes the rest)

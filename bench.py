@@ -187,6 +187,60 @@ def host_cpu():
     return nproc, model
 
 
+def calibrate(dev):
+    """Two figures of THIS box, measured in this process before the timed region (~1 s): the fp32 MFMA rate (lic360_calib_mfma_f32: v_mfma_f32_16x16x4_f32
+    on every CU) and a 1 GiB device-to-device copy -- plus the card's current shader / memory clocks from sysfs where readable.  The boxes of the pool
+    differ by 1-3 %: value / calib_mfma_tflops is what to compare between rounds."""
+    import ctypes as C
+    import glob
+    import torch
+    from lic360 import _lib, _chk
+    out = {}
+    tf, cus = C.c_double(0.0), C.c_int(0)
+    _chk(_lib.lic360_calib_mfma_f32(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.byref(tf), C.byref(cus)))
+    out["calib_mfma_tflops"], out["compute_units"] = tf.value, cus.value
+    n = 1 << 30
+    a, b = torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        b.copy_(a)
+    e1.record()
+    e1.synchronize()
+    out["calib_copy_gbs"] = 4 * 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9        # bytes read + bytes written
+    del a, b
+    torch.cuda.empty_cache()
+    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+        try:
+            for path in sorted(glob.glob("/sys/class/drm/card*/device/" + name)):
+                cur = [ln for ln in open(path).read().splitlines() if ln.strip().endswith("*")]
+                if cur:
+                    out[key] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit()))
+                    break
+        except Exception:                                          # noqa: BLE001  (not readable on every box)
+            pass
+    return out
+
+
+PMC_CLASS_KERNELS = None
+
+
+def pmc_entry_matches_library(cls, entry):
+    """a committed PMC entry is only attached to a bench row when every kernel it names is one the LOADED library runs for that class
+    (lic360_codec_kernel_names): traffic of a kernel that no longer exists must not be reported as this run's"""
+    global PMC_CLASS_KERNELS
+    if PMC_CLASS_KERNELS is None:
+        from lic360 import _lib
+        PMC_CLASS_KERNELS = {}
+        for part in _lib.lic360_codec_kernel_names().decode().split(";"):
+            k, v = part.split("=")
+            PMC_CLASS_KERNELS[k] = set(x.strip() for x in v.split("+"))
+    have = PMC_CLASS_KERNELS.get(cls)
+    names = set(x.strip() for x in str(entry.get("kernel", "")).split("+"))
+    return bool(have) and bool(names) and names <= have
+
+
 def newest_pmc_traffic():
     """(dict, file name) of the newest committed PMC collection profiles/rNN_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes, tools/collect_profiles.sh), newest round first"""
@@ -314,7 +368,8 @@ def run_rank(args):
         return ok
 
     say = progress if rank == 0 else (lambda m: None)
-    say("codecs ready; warm-up + %d timed steps of %d images" % (args.steps, B))
+    calib = calibrate(dev) if rank == 0 else {}
+    say("codecs ready; calibration %s; warm-up + %d timed steps of %d images" % (calib, args.steps, B))
     step = lambda: run(codes, masks, levels, True)
     for _ in range(args.warmup):
         step()
@@ -328,6 +383,19 @@ def run_rank(args):
 
     say("timed region done: %.1f ms per step" % (dt / args.steps * 1e3))
     extras = {}
+    if not args.no_extras and args.masks != "iid":
+        # the same step on the masks of rounds 1-5 (every map cell drawn independently): nothing for the dead-cone skip to find -- the adversarial case
+        ci, mi, li = synth_latents(B, seed0=1000 * rank, kind="iid")
+        o, cdi, mki, lvi = 0, [], [], []
+        for sz in sizes:
+            cdi.append(torch.from_numpy(ci[o:o + sz]).to(dev)); mki.append(torch.from_numpy(mi[o:o + sz]).to(dev)); lvi.append(torch.from_numpy(li[o:o + sz]).to(dev))
+            o += sz
+        run(cdi, mki, lvi)
+        dti = shard.timed(lambda: run(cdi, mki, lvi), args.steps, dev)
+        ok = ok and exact(cdi, mki, lvi)
+        extras["iid_masks"] = {"value": world * B * args.steps * PIXELS / dti / 1e6, "unit": "Mpixel/s", "ms_per_step": dti / args.steps * 1e3,
+                               "note": "the timed step on i.i.d. importance maps (tests/util.py:latent, the workload of rounds 1-5)"}
+        del cdi, mki, lvi
     if not args.no_extras:
         # the latent stream alone (98.6 % of the bytes, 95 % of the MACs): round 1's headline, kept for comparison
         run(codes, masks, levels, False)
@@ -435,6 +503,11 @@ def run_rank(args):
         assert len(out["config"]["workload"]) <= 120
         # the side figures as SCALAR keys of `config` (the driver's record keeps scalars only); the nested forms stay beside them
         flat = out["config"]
+        flat.update(calib)
+        if calib.get("calib_mfma_tflops"):
+            flat["value_per_calib_mfma_tflop"] = out["value"] / calib["calib_mfma_tflops"]
+        if "iid_masks" in extras:
+            flat["iid_masks_mpixel_s"] = extras["iid_masks"]["value"]
         if "latent_stream_only" in extras:
             flat["latent_only_mpixel_s"] = extras["latent_stream_only"]["value"]
         if "config4" in extras:
@@ -448,7 +521,12 @@ def run_rank(args):
             flat["config5_mpixel_s"], flat["config5_ms"] = extras["config5"]["value"], extras["config5"]["ms"]
         out["config"].update(extras)
         say("instrumented passes (per-kernel-class events)")
-        out.update(instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B))
+        inst = instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B)
+        skip = inst.pop("skip")
+        out.update(inst)
+        out["config"]["masks"] = args.masks
+        out["config"]["dead_mac_fraction"] = skip["dead_mac_fraction"]
+        out["config"]["dead_cone_skip"] = skip
         if world == 1 and not args.no_extras:
             si = single_image(codecs[0], icodecs[0], codes[0], masks[0], levels[0], streams[0], istreams[0], mbufs[0][0], dev)
             out["config"]["single_image"] = si
@@ -520,6 +598,46 @@ def single_image(c, ic, code, mask, lv, st, ist, mb, dev):
     return res
 
 
+def chain_macs(layer):
+    """MACs per output POSITION of output group g of one net's layer (mask rule, extension/cconv_ec_cuda.cu:288-290; image borders ignored: the
+    figures below are only ever used as ratios)"""
+    import numpy as np
+    hidden, cin, cout = (0, 1, 4) if layer == 0 else ((1, 4, 3) if layer == 11 else (1, 4, 4))
+    g = np.arange(G)[:, None, None]
+    kh, kw = np.arange(5)[None, :, None], np.arange(5)[None, None, :]
+    return np.clip(g + 4 - kh - kw + hidden, 0, G).sum((1, 2)).astype(np.float64) * cin * cout
+
+
+def executed_fractions(stat_pairs, images):
+    """{kernel class: executed / algorithmic MACs} of the latent nets from the codecs' skip counters (lic360_codec_skip_stats; csrc/need.h): what the
+    dead-cone skip left of the reference's work.  stat_pairs: [(enc [12, 64], dec [12, 64], active)] per codec, images: images per codec."""
+    import numpy as np
+    ntiles = ((H + 3) // 4) * ((W + 15) // 16)
+    num = {k: 0.0 for k in ("ec_first", "ec_hidden", "ec_last", "dc_first", "dc_hidden", "dc_last")}
+    den = dict(num)
+    for (enc, dec, active), b in zip(stat_pairs, images):
+        if not b:
+            continue
+        for l in range(12):
+            cm = chain_macs(l)
+            full = 3.0 * b * H * W * cm.sum()
+            cls = "first" if l == 0 else ("last" if l == 11 else "hidden")
+            for side in ("ec_", "dc_"):
+                den[side + cls] += full
+            # encode order: live (tile, group block) pairs, 64 positions each, of N samples (last layer: the three nets of a pair run as phases)
+            if active >= 1 and l > 0:
+                gpb, rep = (5, 3.0) if l == 11 else (4, 1.0)
+                wgb = np.array([cm[i:i + gpb].sum() for i in range(0, G, gpb)])
+                num["ec_" + cls] += rep * 64.0 * float((enc[l, :len(wgb)].astype(np.float64) * wgb).sum()) * (H * W / (64.0 * ntiles))
+            else:
+                num["ec_" + cls] += full
+            if active >= 2 and l > 0 and b % 8 == 0 and b >= 16:
+                num["dc_" + cls] += float((dec[l, :G].astype(np.float64) * cm).sum())
+            else:
+                num["dc_" + cls] += full
+    return {k: (num[k] / den[k] if den[k] else 1.0) for k in num}
+
+
 def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, B):
     """Per-kernel-class durations from HIP events on the launch stream: (a) one sub-batch ALONE on the GPU, (b) all streams."""
     import torch
@@ -534,6 +652,14 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
                 codecs[i].decode_async(masks[i], codes[i].shape[0])
         torch.cuda.synchronize(dev)
 
+    # what the dead-cone skip executes (an untimed pass of its own: the counters are atomics): sub-batch 0 for the isolated rows, all for the step
+    for c in codecs:
+        c.skip_stats(True)
+    one_pass(range(len(codecs)))
+    stat_pairs = [c.skip_stats(False, read=True) + (c.skip_active(),) for c in codecs]
+    imgs = [int(cd.shape[0]) for cd in codes]
+    ex0 = executed_fractions(stat_pairs[:1], imgs[:1])
+    ex_all = executed_fractions(stat_pairs, imgs)
     codecs[0].profile(True)
     one_pass([0])
     iso = codecs[0].profile_read()
@@ -557,9 +683,11 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
         row = {"kernel": cls, "launches": n, "avg_launch_ms": ms / n, "images_per_launch": b0, "total_ms": ms}
         part = cls.split("_", 1)[1] if cls[:3] in ("ec_", "dc_") else None
         if part in GMAC:
-            fl = 2 * GMAC[part] * 1e9 * b0                         # whole pass of this class over b0 images, one direction
-            row.update(bound="mfma", achieved=fl / (ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                       algorithmic_flops_per_launch=fl / n)
+            fl = 2 * GMAC[part] * 1e9 * b0                         # whole pass of this class over b0 images, one direction: the reference's count
+            fx = fl * ex0.get(cls, 1.0)                            # ... and what was executed of it (dead-cone skip): achieved / frac are priced on THIS
+            row.update(bound="mfma", achieved=fx / (ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                       algorithmic_flops_per_launch=fl / n, executed_flops_per_launch=fx / n, executed_fraction=ex0.get(cls, 1.0),
+                       reference_work_rate={"value": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "note": "the reference's MACs of this pass / its time (skipped work counted as done: a speed, not an efficiency)"})
         elif cls in ("enc_tables", "dec_tables"):
             per_sym = 52.0 if cls == "enc_tables" else 56.0        # 9 floats of net output + symbol/mask in; (lo,hi) record or 7 packed 16-bit entries + flag out
             by = per_sym * NSYM * b0
@@ -597,7 +725,13 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
     for r in rows:
         pm = pmc.get(r["kernel"])
         if isinstance(pm, dict):
-            r["traffic"] = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
+            if pmc_entry_matches_library(r["kernel"], pm):
+                r["traffic"] = pm["traffic_bytes_per_launch"] * b0 / pm["images_per_launch"]
+                if pmc.get("masks") and pmc.get("masks") != args.masks:
+                    r["traffic_note"] = "collected on %s masks" % pmc.get("masks")
+            else:
+                r["traffic"] = None
+                r["traffic_note"] = "profiles/%s names kernels (%s) the loaded library does not run for this class: re-collect (tools/collect_profiles.sh)" % (pmc_file, pm.get("kernel"))
         if r["kernel"] == "ec_last" and "enc_tables" not in iso_live:
             # the fused last layer + CDF-table kernel (N1): HBM view next to the MFMA view.  Algorithmic bytes: 3 nets x 4 channels in,
             # symbol + mask in, one (cdf[sym], cdf[sym+1]) record out = 64 B per symbol, + the layer's weights once per launch
@@ -608,24 +742,34 @@ def instrumented(args, codecs, icodecs, codes, masks, levels, streams, dev, dt, 
                              "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": by / (r["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     traffic = dom.get("traffic")
     conv_ms = sum(r["total_ms"] for r in convs)
+    cls_gmac = {"ec_first": GMAC["first"], "ec_hidden": GMAC["hidden"], "ec_last": GMAC["last"], "dc_first": GMAC["first"], "dc_hidden": GMAC["hidden"], "dc_last": GMAC["last"]}
+    exec_net0 = sum(cls_gmac[k] * ex0[k] for k in cls_gmac)            # executed GMAC per image, both directions (sub-batch 0 / whole batch)
+    exec_net = sum(cls_gmac[k] * ex_all[k] for k in cls_gmac)
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["frac"], "traffic": traffic,
                 "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes of tools/collect_profiles.sh, not collected in this run), scaled to "
                                    "%d images per launch" % (pmc_file, b0)) if traffic is not None else None,
-                "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
+                "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"], "executed_flops_per_launch": dom["executed_flops_per_launch"],
+                "executed_fraction": dom["executed_fraction"],
+                "accounting": "achieved / frac = EXECUTED flops (the reference's count minus what the dead-cone skip did not compute, from the codec's own counters) / kernel time",
                 "images_per_launch": b0, "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
                 "how": "one sub-batch alone on the GPU, one stream, HIP events around every launch on the launch stream (instrumented pass, "
                        "outside the timed region)",
-                "rocprof_kernel_names": "dc_hidden / dc_last launches run as k_cconv4v6t<4> (planes that tape-pack their samples) or k_cconv4v6<4, false, false> "
-                                        "(full-length planes); profiles/*_dc_isolated_kernel_stats.csv lists both, their call-weighted mean is this class",
+                "rocprof_kernel_names": "dc_hidden / dc_last launches run as k_cconv4v6l<4> (task records from the dead-cone lists: batches of >= 16 images) -- "
+                                        "or, without lists, k_cconv4v6t<4> (planes that tape-pack their samples) / k_cconv4v6<4, false, false> (full-length planes)",
                 "concurrent": {"avg_launch_ms": dom.get("avg_launch_ms_concurrent"), "streams": len(codecs),
                                "note": "same kernel while the other streams' kernels share the CUs (the timed region's regime)"},
-                "all_conv_layers_isolated": {"achieved": 2 * 2 * NET_GMAC * 1e9 * b0 / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
-                                             "frac": 2 * 2 * NET_GMAC * 1e9 * b0 / (conv_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
-                "whole_step": {"achieved": 2 * 2 * (NET_GMAC + IMP_GMAC) * 1e9 * B / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
-                               "frac": 2 * 2 * (NET_GMAC + IMP_GMAC) * 1e9 * B / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                               "note": "algorithmic FLOPs of every conv layer (both nets, both directions) / wall time of the timed step"}}
-    return {"roofline": roofline, "kernels": rows}
+                "all_conv_layers_isolated": {"achieved": 2 * exec_net0 * 1e9 * b0 / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                             "frac": 2 * exec_net0 * 1e9 * b0 / (conv_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
+                "whole_step": {"achieved": 2 * (exec_net + 2 * IMP_GMAC) * 1e9 * B / (dt / args.steps) / 1e12, "unit": "TFLOP/s",
+                               "frac": 2 * (exec_net + 2 * IMP_GMAC) * 1e9 * B / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                               "note": "EXECUTED FLOPs of every conv layer (both nets, both directions) / wall time of the timed step"}}
+    skip = {"dead_mac_fraction": 1.0 - exec_net / (2 * NET_GMAC), "executed_fraction_by_class": ex_all,
+            "skip_active": [p[2] for p in stat_pairs],
+            "note": "share of the latent nets' MACs (reference count, both directions, whole per-GPU batch) that no coded symbol can observe AND that the "
+                    "kernels' granularity (encode: 4 x 16 tile x group block; decode: hull of a sample's live rows per three-group block and plane) let "
+                    "them skip; csrc/need.h"}
+    return {"roofline": roofline, "kernels": rows, "skip": skip}
 
 
 def main():

@@ -30,6 +30,9 @@ int lic360_version(void);
 int lic360_sphere_pad(void *stream, const float *x, float *out, int nc, int h, int w, int pad);
 /* SpherePadOp.forward, inplace=true          extension/sphere_pad_cuda.cu:48-65; hp,wp = padded dims */
 int lic360_sphere_pad_inplace(void *stream, float *x, int nc, int hp, int wp, int pad);
+/* SphereTrimOp.forward then SpherePadOp.forward(inplace) of the same width on the same tensor, as the reference's blocks run them back to back
+ * (test/model_zoo.py:83-84,90-91,160-161): the refresh overwrites every cell the trim zeroed, so the pair is ONE pass over the apron */
+int lic360_sphere_trim_pad_inplace(void *stream, float *x, int nc, int hp, int wp, int pad);
 /* SphereTrimOp.forward                       extension/sphere_trim_cuda.cu:28-46 */
 int lic360_sphere_trim(void *stream, float *x, int nc, int h, int w, int pad);
 /* SphereCutEdgeOp.forward                    extension/sphere_cut_edge_cuda.cu:43-62 */
@@ -377,9 +380,15 @@ int lic360_codec_skip_stats(lic360_codec *codec, int enable, unsigned long long 
 int lic360_codec_debug_fill(void *stream, lic360_codec *codec, float value);
 int lic360_codec_debug_lists(lic360_codec *codec, int which, void *host_out, long bytes, int *cap_out);
 
+/* calibration for bench.py (no reference counterpart): the fp32 MFMA rate (v_mfma_f32_16x16x4_f32, 8 waves per CU) this device sustains right now, in
+ * TFLOP/s, and its compute-unit count; ~50 ms.  bench.py prints it beside the headline so that figures of different boxes of a pool can be normalised. */
+int lic360_calib_mfma_f32(void *stream, double *tflops, int *cus_out);
+
 /* timing hooks for bench.py's instrumented pass: HIP events around every launch of each kernel class of the codec
  * (classes() names them, comma separated: first / hidden / last conv layers in both orders, table builds, coder kernels),
  * recorded on the caller's stream; read() fills ms[k] / launches[k] per class (n >= number of classes) and resets */
+/* the kernels behind each kernel class of the timing hooks, "class=kernel+kernel;..." (names as rocprofv3 prints them) */
+const char *lic360_codec_kernel_names(void);
 int lic360_codec_profile_enable(lic360_codec *codec, int on);
 const char *lic360_codec_profile_classes(void);
 int lic360_codec_profile_read(lic360_codec *codec, int n, double *ms, long *launches);

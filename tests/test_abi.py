@@ -52,3 +52,16 @@ def test_layout_queries_and_buffer_sizes_run_without_a_gpu():
     for h, w in ((32, 64), (64, 128), (5, 3)):
         assert L.lic360_dc144_layout(h, w, ctypes.byref(rows), ctypes.byref(pitch)) == 0
         assert rows.value == h + w - 1 + 8 and pitch.value % 4 == 0 and pitch.value >= h + 36
+
+
+def test_kernel_names_of_the_bench_classes_exist_in_the_library():
+    """bench.py attaches committed PMC traffic to a kernel class only when the entry's kernels are the ones lic360_codec_kernel_names lists
+    for it; every base name listed there must be a kernel of the loaded library (its mangled name holds the base name)"""
+    import lic360
+    blob = open(lic360.LIBRARY_PATH, "rb").read()
+    classes = dict(p.split("=") for p in lic360._lib.lic360_codec_kernel_names().decode().split(";"))
+    assert set(classes) == {"ec_first", "ec_hidden", "ec_last", "dc_first", "dc_hidden", "dc_last", "imp_ec", "imp_dc"}
+    for cls, names in classes.items():
+        for name in names.split("+"):
+            base = name.split("<")[0].strip()
+            assert ("%d%s" % (len(base), base)).encode() in blob, (cls, name)       # Itanium mangling: <length><identifier>

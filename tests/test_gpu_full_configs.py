@@ -86,3 +86,33 @@ def test_batch_of_cfg3_images():
     streams = fc.encode(dev(code8), dev(mask8))
     assert streams[0] == g["bytes"].tobytes() and streams[1] == gb["bytes"].tobytes()
     assert np.array_equal(fc.decode(streams, dev(mask8)).cpu().numpy(), code8 * mask8)
+
+
+def test_container_round_trip_of_the_fused_codecs_bitstreams(tmp_path):
+    """row f2: the two bitstreams the FusedCodec / FusedImpCodec produce for cfg2s, packed into the single-file container, written,
+    read back, unpacked -- the payloads are the oracle's bytes (what the reference would have written to `<code>` and `<code>_imp`,
+    test/lic360_demo.py:361-365) -- and decoded on the GPU from the unpacked payloads: map first, the latent under the mask the decoded map gives."""
+    import lic360_container as box
+    g, shape, code, mask, levels, layers, imp_layers = load("cfg2s")
+    G, H, W = shape
+    fc, ic = codecs(shape, layers, imp_layers)
+    lat, imp = fc.encode(dev(code), dev(mask))[0], ic.encode(dev(levels))[0]
+    path = str(tmp_path / "erp.l360")
+    box.write_file(path, lat, imp, 8 * H, 8 * W, model_idx=0, ssim=False)
+    d = box.read_file(path)
+    assert (d["height"], d["width"], d["model_idx"], d["ssim"]) == (512, 1024, 0, False)
+    assert d["latent"] == g["bytes"].tobytes() and d["imp"] == g["imp_bytes"].tobytes()
+    # the reference's two-file form and back
+    box.to_reference_files(open(path, "rb").read(), str(tmp_path / "code"))
+    assert open(str(tmp_path / "code"), "rb").read() == g["bytes"].tobytes() and open(str(tmp_path / "code_imp"), "rb").read() == g["imp_bytes"].tobytes()
+    lv = ic.decode([d["imp"]])
+    assert np.array_equal(lv.cpu().numpy(), levels)
+    import lic360
+    m2 = lic360.DtowOp(2, True, 0, False).forward(lic360.Imp2maskOp(48, 192, 0, False).forward(lv)[0])[0]     # lic360_demo.py:283-287
+    assert np.array_equal(m2.cpu().numpy(), mask)
+    out = fc.decode([d["latent"]], m2.contiguous()).cpu().numpy()
+    assert np.array_equal(out, code * mask)
+    bad = bytearray(open(path, "rb").read())
+    bad[40] ^= 0x10
+    with pytest.raises(box.ContainerError):
+        box.unpack(bytes(bad))

@@ -4,12 +4,12 @@ sys.path.insert(0, "360-image-compression_amd"); sys.path.insert(0, "oracle"); s
 import torch, numpy as np
 import ref_codec as rc
 from lic360_fused import FusedCodec
-from util import latent
+from util import make_latent
 G, H, W = 48, 128, 256
 B = int(os.environ.get("PB", "8"))
 layers = rc.make_main_params(1007, G)
 fc = FusedCodec(G, H, W, max_batch=B); fc.load_layers(layers)
-items = [latent(np.random.default_rng(i), G, H, W) for i in range(B)]
+items = [make_latent(os.environ.get("MASKS", "smooth"), np.random.default_rng(i), G, H, W) for i in range(B)]   # MASKS=iid: the masks of rounds 1-5
 code = torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask = torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.time()

@@ -4,11 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("360-image-compression_amd", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import torch, numpy as np
-from util import latent, make_main_params
+from util import make_latent, make_main_params
 from lic360_fused import FusedCodec
 G, H, W, B = 48, 64, 128, int(os.environ.get("PB", 1))
 fc = FusedCodec(G, H, W, max_batch=B); fc.load_layers(make_main_params(1003, G))
-items = [latent(np.random.default_rng(i), G, H, W) for i in range(B)]
+items = [make_latent(os.environ.get("MASKS", "smooth"), np.random.default_rng(i), G, H, W) for i in range(B)]   # MASKS=iid: the masks of rounds 1-5
 code = torch.from_numpy(np.concatenate([i[0] for i in items])).cuda(); mask = torch.from_numpy(np.concatenate([i[1] for i in items])).cuda()
 st = torch.cuda.Stream()
 fc.encode_async(code, mask); torch.cuda.synchronize()
