@@ -18,6 +18,9 @@
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <thread>
+#include <atomic>
+#include <immintrin.h>
 
 struct AcDevState {            // per-image decoder state carried across planes
     uint32_t low, high, code;
@@ -61,6 +64,14 @@ struct lic360_codec {
     lic360_dc_lists dcl;
     unsigned long long *stats = nullptr;       // [2][12][NEED_STAT_G]: live tiles per (layer, group block) of the encodes, stored cells per (layer, group) of the decodes
     bool stats_on = false;
+    // Host leg of the arithmetic coder (round 6; the reference's own division of labour: extension/coder.cpp:70-113 runs on the CPU).  One wave per image
+    // is the slowest possible coder -- 27.6 ms per image to encode, ~170 us per plane to decode -- and only hides behind other images' convolutions; a
+    // host thread does 21 / 29 ns per symbol.  With few images per call (<= coder_auto_max) the serial phases therefore run on host threads:
+    // encode -- records D2H, one thread per image, bitstreams H2D; decode -- per plane the packed tables go to pinned memory, one persistent thread per
+    // image decodes its symbols, a GPU kernel waits for them on polled flags (no API call, no stream synchronisation per plane).
+    int coder_mode = 2;                        // 0 device, 1 host, 2 auto (host when B <= coder_auto_max); LIC360_HOST_CODER=0|1 overrides at create
+    int coder_auto_max = 16;
+    struct HostLeg *hl = nullptr;
     // optional per-kernel-class timing (bench.py's instrumented pass; off in the timed region): HIP event pairs around
     // every launch of a class, recorded on the launch stream
     bool prof = false;
@@ -664,6 +675,225 @@ static int dmalloc(T **p, size_t n) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ host leg of the coder (latency regime)
+// Pinned, host-coherent buffers + polled flags between the GPU and one host thread per image; see lic360_codec::coder_mode.
+#define HL_FB 16                               // flags: [0] tables of plane `seq` are in tab_h, [1] bitstreams of decode `gen` are in bytes_h, [2] abort,
+#define HL_MAXB 64                             //        [HL_FB + i] image i's symbols of plane `seq` are in sym_h
+#define HL_SPIN_LIMIT 400000L                  // polls of a GPU-side wait before it gives up (~1 s): a dead host thread is an error, never a hang
+struct HostLeg {
+    int maxB = 0, tab_pitch = 0;
+    long cap = 0, nsym = 0;
+    uint2 *rec_h = nullptr;                    // [maxB][nsym] (cdf[sym], cdf[sym + 1]) records of an encode
+    uint8_t *bytes_h = nullptr;                // [maxB][cap]
+    int *nbytes_h = nullptr, *err_h = nullptr;
+    unsigned short *tab_h = nullptr;           // [maxB][tab_pitch][8]: coded flag, T[1..7] of the current plane's symbols
+    float *sym_h = nullptr;                    // [maxB][tab_pitch]: decoded symbols of the current plane (-1: not coded)
+    int *flags = nullptr;
+    int *d_ctr = nullptr;                      // device: arrival counter of the table kernel's workgroups
+    int gen = 0;
+    std::vector<std::thread> workers;
+};
+static inline int hl_ld(const int *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void hl_st(int *p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static void hl_join(HostLeg *h) {
+    for (std::thread &t : h->workers) if (t.joinable()) t.join();
+    h->workers.clear();
+}
+static void hl_free(HostLeg *h) {
+    if (!h) return;
+    if (h->flags) hl_st(h->flags + 2, 1);                                 // release whoever still polls
+    hl_join(h);
+    (void)hipDeviceSynchronize();
+    (void)hipHostFree(h->rec_h); (void)hipHostFree(h->bytes_h); (void)hipHostFree(h->nbytes_h); (void)hipHostFree(h->err_h);
+    (void)hipHostFree(h->tab_h); (void)hipHostFree(h->sym_h); (void)hipHostFree(h->flags); (void)hipFree(h->d_ctr);
+    delete h;
+}
+template <class T>
+static int hl_alloc(T **p, size_t n) {
+    HIP_TRY(hipHostMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
+    return 0;
+}
+// buffers for B images of nsym symbols, bitstream slots of cap bytes, planes of at most tab_pitch symbols (grown on demand; growing synchronises)
+static int hl_get(lic360_codec *c, int B, long cap, HostLeg **out) {
+    ARG_CHECK(B > 0 && B <= HL_MAXB);
+    HostLeg *h = c->hl;
+    const long nsym = (long)c->G * c->HW;
+    if (h && (h->maxB < B || h->cap < cap)) { hl_free(h); h = c->hl = nullptr; }
+    if (!h) {
+        h = new HostLeg();
+        c->hl = h;
+        h->maxB = std::max(B, std::min(c->maxB, HL_MAXB)); h->cap = cap; h->nsym = nsym; h->tab_pitch = c->tab_pitch;
+        int rc = hl_alloc(&h->rec_h, (size_t)h->maxB * nsym) | hl_alloc(&h->bytes_h, (size_t)h->maxB * cap) | hl_alloc(&h->nbytes_h, h->maxB) |
+                 hl_alloc(&h->err_h, h->maxB) | hl_alloc(&h->tab_h, (size_t)h->maxB * h->tab_pitch * 8) | hl_alloc(&h->sym_h, (size_t)h->maxB * h->tab_pitch) |
+                 hl_alloc(&h->flags, HL_FB + HL_MAXB) | dmalloc(&h->d_ctr, 1);
+        if (rc) return 1;
+        memset(h->flags, 0, (HL_FB + HL_MAXB) * sizeof(int));
+        HIP_TRY(hipMemset(h->d_ctr, 0, sizeof(int)));
+    }
+    *out = h;
+    return 0;
+}
+
+// ---- encode: the records of the fused last layer, one host thread per image (ac_core.h: the coder the drop-in `Coder` runs)
+struct HlEncJob { HostLeg *h; int B; long n, cap; };
+static void hl_encode_image(HostLeg *h, int i, long n, long cap) {
+    const uint2 *r = h->rec_h + (long)i * n;
+    AcState st;
+    ac_init(st);
+    AcBitWriter bw;
+    ac_bw_init(bw, h->bytes_h + (long)i * h->cap, cap);
+    for (long k = 0; k < n; ++k) {
+        const uint2 v = r[k];
+        if (v.y) ac_encode_symbol(st, bw, v.x, v.y, 65536u);             // hi == 0: not coded (mask < 0.5, coder.cpp:79)
+    }
+    ac_encode_finish(st, bw);
+    h->nbytes_h[i] = (int)bw.len;
+    h->err_h[i] = st.error | (bw.len > cap ? 16 : 0);
+}
+static void hl_encode_all(void *ud) {                                   // (a stream callback: no HIP call in here)
+    HlEncJob *j = (HlEncJob *)ud;
+    std::vector<std::thread> th;
+    for (int i = 1; i < j->B; ++i) th.emplace_back(hl_encode_image, j->h, i, j->n, j->cap);
+    hl_encode_image(j->h, 0, j->n, j->cap);
+    for (std::thread &t : th) t.join();
+    delete j;
+}
+static int hl_encode(lic360_codec *c, hipStream_t s, int B, uint8_t *bytes, long cap, int *nbytes, int *err) {
+    HostLeg *h;
+    if (hl_get(c, B, cap, &h)) return 1;
+    const long n = (long)c->G * c->HW;
+    HIP_TRY(hipMemcpyAsync(h->rec_h, c->e_rec, (size_t)B * n * sizeof(uint2), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipLaunchHostFunc(s, hl_encode_all, new HlEncJob{h, B, n, cap}));
+    HIP_TRY(hipMemcpy2DAsync(bytes, (size_t)cap, h->bytes_h, (size_t)h->cap, (size_t)cap, (size_t)B, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(nbytes, h->nbytes_h, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(err, h->err_h, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// ---- decode: per plane  k_dec_tables_host -> (host threads) -> k_dec_wait_scatter
+struct DecTablesHostArgs {
+    const float *y, *mask;
+    const int *idx;
+    int start, len, p;
+    uint4 *tab;                                 // pinned: [B][tab_pitch] x 8 halves
+    int tab_pitch, B, G, H, W, sk_rows, sk_pitch, sk_row0, sk_col0;
+    int *ctr, *flag;
+    int seq, nblocks;
+};
+__global__ __launch_bounds__(64) void k_dec_tables_host(const DecTablesHostArgs a) {
+    const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    if (i < a.len) {
+        const int HW = a.H * a.W;
+        const long SK = (long)a.sk_rows * a.sk_pitch;
+        const int q = a.start + i;
+        const int th = a.idx[q], tw = a.idx[q + HW], g = a.p - th - tw;
+        const long nchw = (((long)b * a.G + g) * a.H + th) * a.W + tw;
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (!(a.mask[nchw] < 0.5f)) {                                    // coder.cpp:79
+            float v[9];
+#pragma unroll
+            for (int net = 0; net < 3; ++net)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[net * 3 + c] = a.y[((long)(net * a.B + b) * (3 * a.G) + g * 3 + c) * SK + (long)(th + tw + a.sk_row0) * a.sk_pitch + th + a.sk_col0];
+            int T[9];
+            gmm_cdf9(v, v + 3, v + 6, T);                                // 0 = T[0] < T[1] < ... < T[8] = 65536: the inner entries fit 16 bits
+            r = make_uint4(1u | (unsigned)T[1] << 16, (unsigned)T[2] | (unsigned)T[3] << 16, (unsigned)T[4] | (unsigned)T[5] << 16, (unsigned)T[6] | (unsigned)T[7] << 16);
+        }
+        a.tab[(long)b * a.tab_pitch + i] = r;
+    }
+    // the last workgroup to arrive publishes the plane (lane 0 of a workgroup always owns a symbol)
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(a.ctr, 1) == a.nblocks - 1) {
+            atomicExch(a.ctr, 0);
+            __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+struct DecWaitArgs {
+    int *flags;
+    const float *sym;
+    int seq, B, tab_pitch;
+    const int *idx;
+    int start, len, p;
+    float *x0, *code_out;
+    int G, H, W, sk_rows, sk_pitch, sk_row0, sk_col0;
+};
+__global__ __launch_bounds__(1024) void k_dec_wait_scatter(const DecWaitArgs a) {
+    __shared__ int s_abort;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+    if (tid < a.B) {                                                    // thread i waits for image i's host thread; every poll is a read of pinned host memory
+        long spins = 0;
+        while (__hip_atomic_load(a.flags + HL_FB + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            if (__hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || ++spins > HL_SPIN_LIMIT) { s_abort = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (s_abort) {                                                      // sticky: every later wait of this decode returns at once, err[] reports it
+        if (tid == 0) __hip_atomic_store(a.flags + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const int HW = a.H * a.W;
+    const long SK = (long)a.sk_rows * a.sk_pitch;
+    for (int e = tid; e < a.B * a.len; e += 1024) {
+        const int b = e / a.len, j = e - b * a.len;
+        const float v = a.sym[(long)b * a.tab_pitch + j];
+        const bool coded = v >= 0.0f;
+        const int th = a.idx[a.start + j], tw = a.idx[a.start + j + HW], g = a.p - th - tw;
+        a.x0[((long)b * a.G + g) * SK + (long)(th + tw + a.sk_row0) * a.sk_pitch + th + a.sk_col0] = coded ? v - 3.5f : 0.0f;   // = TileInput + `b[0:1] + 3.5*mask` (lic360_demo.py:222,236-237)
+        a.code_out[(((long)b * a.G + g) * a.H + th) * a.W + tw] = coded ? v : 0.0f;
+    }
+}
+__global__ void k_hl_signal(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ void k_hl_err(const int *err_h, const int *flags, int *err, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) err[b] = err_h[b] | (__hip_atomic_load((int *)flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 128 : 0);   // 128: the host leg was aborted
+}
+// the thread of image i: ArithmeticDecoder::read (ArithmeticCoder.cpp:82-116) on the tables the GPU publishes plane by plane
+static void hl_decode_worker(HostLeg *h, int i, long cap, int gen, std::vector<int> lens) {
+    int *flags = h->flags;
+    auto wait = [&](const int *f, int v) {
+        while (hl_ld(f) < v) {
+            if (hl_ld(flags + 2)) return false;
+            _mm_pause();
+        }
+        return true;
+    };
+    if (!wait(flags + 1, gen)) return;
+    long len = h->nbytes_h[i];
+    int e0 = 0;
+    if (len < 0) { len = 0; e0 = 32; }
+    if (len > cap) { len = cap; e0 = 32; }                               // the stream length is never trusted (error bit 32 flags a clamp)
+    AcBitReader rd;
+    ac_br_init(rd, h->bytes_h + (long)i * h->cap, len);
+    AcState st;
+    ac_init(st);
+    ac_decode_start(st, rd);
+    const int seq0 = gen << 13;
+    for (int p = 0; p < (int)lens.size(); ++p) {
+        const int ln = lens[p];
+        if (ln <= 0) continue;
+        if (!wait(flags, seq0 + p + 1)) return;
+        const unsigned short *t = h->tab_h + (long)i * h->tab_pitch * 8;
+        float *o = h->sym_h + (long)i * h->tab_pitch;
+        for (int j = 0; j < ln; ++j, t += 8) {
+            if (!t[0]) { o[j] = -1.0f; continue; }
+            const uint32_t target = ac_decode_target(st, 65536u);
+            int sym = 0;
+#pragma GCC unroll 7
+            for (int k = 1; k < 8; ++k) sym += (uint32_t)t[k] <= target;
+            ac_decode_consume(st, rd, sym ? t[sym] : 0u, sym == 7 ? 65536u : t[sym + 1], 65536u);
+            o[j] = (float)sym;
+        }
+        h->err_h[i] = e0 | st.error;
+        hl_st(flags + HL_FB + i, seq0 + p + 1);
+    }
+}
+
 LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic360_codec **out) {
     ARG_CHECK(out && ngroup > 0 && ngroup < 128 && h > 0 && w > 0 && h < 4096 && w < 4096 && max_batch > 0);
     lic360_codec *c = new lic360_codec();
@@ -718,6 +948,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
     for (int p = 0; p < c->P; ++p) c->tab_pitch = std::max(c->tab_pitch, c->h_plane_start[p + 1] - c->h_plane_start[p]);
     c->tab_pitch = (c->tab_pitch + 63) / 64 * 64;
     rc |= dmalloc(&c->d_tab, 2 * B * (size_t)c->tab_pitch);                 // two uint4 per symbol (dec_pack8)
+    if (const char *hc = getenv("LIC360_HOST_CODER")) c->coder_mode = hc[0] == '0' ? 0 : (hc[0] == '1' ? 1 : 2);
     c->skip = c->use4 && !getenv("LIC360_NOSKIP");
     if (c->skip) {
         const size_t S = c->S, nt = (size_t)((h + 3) / 4) * ((w + 15) / 16);
@@ -752,6 +983,7 @@ LIC360_API int lic360_codec_create(int ngroup, int h, int w, int max_batch, lic3
 
 LIC360_API void lic360_codec_destroy(lic360_codec *c) {
     if (!c) return;
+    hl_free(c->hl);
     for (int i = 0; i < 3; ++i) lic360_conv_plan_destroy(c->plan[i]);
     for (int i = 0; i < 12; ++i) { (void)hipFree(c->packed[i]); (void)hipFree(c->bias[i]); (void)hipFree(c->act[i]); (void)hipFree(c->packed4[i]); }
     (void)hipFree(c->d_idx); (void)hipFree(c->d_pidx); (void)hipFree(c->d_plane_start);
@@ -789,6 +1021,16 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
     return 0;
 }
 
+static bool coder_on_host(const lic360_codec *c, int B) {
+    return c->coder_mode == 1 ? B <= HL_MAXB : (c->coder_mode == 2 && B <= c->coder_auto_max);
+}
+// 0: the serial coder phases run on the GPU (one wave per image), 1: on host threads (B <= 64), 2: auto -- host for calls of at most 16 images (the
+// latency regime: the GPU coder only pays where other images' convolutions hide it)
+LIC360_API int lic360_codec_set_coder(lic360_codec *c, int mode) {
+    ARG_CHECK(c && mode >= 0 && mode <= 2);
+    c->coder_mode = mode;
+    return 0;
+}
 static int check_ready(const lic360_codec *c, int B) {
     ARG_CHECK(c && B > 0 && B <= c->maxB);
     for (int i = 0; i < 12; ++i)
@@ -838,6 +1080,10 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
         PROF(c, PROF_EC_LAST, s, rc |= lic360_cconv16_ec_tables(stream, c->plan[2], cur, c->packed16[11], c->bias[11], code, mask, c->d_pidx,
                                                                 c->d_plane_start, c->e_rec, B, H, W, c->e_ctr));
         if (rc) return 1;
+        if (coder_on_host(c, B)) {
+            PROF(c, PROF_AC_ENCODE, s, rc |= hl_encode(c, s, B, bytes, cap, nbytes, err));
+            return rc ? 1 : 0;
+        }
         PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
         LAUNCH_CHECK();
         return 0;
@@ -847,6 +1093,10 @@ LIC360_API int lic360_codec_encode(void *stream, lic360_codec *c, const float *c
     PROF(c, PROF_ENC_TABLES, s, hipLaunchKernelGGL(k_enc_tables, dim3(lic360_blocks(total, 1)), dim3(256), 0, s, t1, code, mask, c->d_pidx,
                                                    c->d_plane_start, c->e_rec, B, G, H, W, c->e_hp, c->e_wp, c->e_off));
     LAUNCH_CHECK();
+    if (coder_on_host(c, B)) {
+        PROF(c, PROF_AC_ENCODE, s, rc |= hl_encode(c, s, B, bytes, cap, nbytes, err));
+        return rc ? 1 : 0;
+    }
     PROF(c, PROF_AC_ENCODE, s, hipLaunchKernelGGL(k_ac_encode, dim3(B), dim3(128), 0, s, c->e_rec, (long)G * c->HW, bytes, cap, nbytes, err));
     LAUNCH_CHECK();
     return 0;
@@ -858,9 +1108,33 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
     ARG_CHECK(bytes && nbytes && mask && code_out && err && cap > 0 && cap < (1L << 31) && cap % 4 == 0 && ((uintptr_t)bytes & 3) == 0);
     hipStream_t s = (hipStream_t)stream;
     const int G = c->G, H = c->H, W = c->W;
-    hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
-    LAUNCH_CHECK();
     const int *pih = c->h_pidx.data();
+    // the serial decoder: one wave per image on the GPU, or one host thread per image fed through pinned memory (few images per call)
+    const bool host = coder_on_host(c, B);
+    HostLeg *h = nullptr;
+    int seq0 = 0;
+    if (host) {
+        ARG_CHECK(c->P < (1 << 13));
+        if (hl_get(c, B, cap, &h)) return 1;
+        hl_join(h);                                                     // the previous decode's threads end with its last plane
+        if (hl_ld(h->flags + 2) || h->gen >= (1 << 17)) {               // an aborted decode, or the sequence numbers run out: nothing polls after a synchronisation
+            HIP_TRY(hipDeviceSynchronize());
+            memset(h->flags, 0, (HL_FB + HL_MAXB) * sizeof(int));
+            h->gen = 0;
+        }
+        const int gen = ++h->gen;
+        seq0 = gen << 13;
+        HIP_TRY(hipMemcpy2DAsync(h->bytes_h, (size_t)h->cap, bytes, (size_t)cap, (size_t)cap, (size_t)B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->nbytes_h, nbytes, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_hl_signal, dim3(1), dim3(1), 0, s, h->flags + 1, gen);
+        LAUNCH_CHECK();
+        std::vector<int> lens(c->P);
+        for (int p = 0; p < c->P; ++p) { int st0, ln; lic360_plane_window(p, G, H, W, pih, &st0, &ln); lens[p] = ln; }
+        for (int i = 0; i < B; ++i) h->workers.emplace_back(hl_decode_worker, h, i, cap, gen, lens);
+    } else {
+        hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
+        LAUNCH_CHECK();
+    }
     // dead-cone skip: the whole mask must be final before the first plane (a gated decode waits for the map's LAST event instead of plane by plane)
     const bool lists = c->skip && c->dcl.list && B % 8 == 0 && B >= 16;
     if (lists) {
@@ -899,6 +1173,16 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
             const int q = std::min(n_gate - 1, p / gate_stride);
             if (q != gate_q) { HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)gate[q], 0)); gate_q = q; }
         }
+        if (host) {
+            const int nblk = (len + 63) / 64 * B;
+            PROF(c, PROF_DEC_TABLES, s, hipLaunchKernelGGL(k_dec_tables_host, dim3((len + 63) / 64, B), dim3(64), 0, s, DecTablesHostArgs{c->d_y, mask, c->d_idx, start, len, p,
+                                                           (uint4 *)h->tab_h, h->tab_pitch, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0, h->d_ctr, h->flags, seq0 + p + 1, nblk}));
+            LAUNCH_CHECK();
+            PROF(c, PROF_DEC_PLANE, s, hipLaunchKernelGGL(k_dec_wait_scatter, dim3(1), dim3(1024), 0, s, DecWaitArgs{h->flags, h->sym_h, seq0 + p + 1, B, h->tab_pitch, c->d_idx, start, len, p,
+                                                          c->d_x0, code_out, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0}));
+            LAUNCH_CHECK();
+            continue;
+        }
         PROF(c, PROF_DEC_TABLES, s, hipLaunchKernelGGL(k_dec_tables, dim3((len + 63) / 64, B), dim3(64), 0, s, DecTablesArgs{c->d_y, mask, c->d_idx, start, len, p,
                                                        c->d_tab, c->tab_pitch, B, G, H, W, c->sk_rows, c->sk_pitch, c->sk_row0, c->sk_col0}));
         LAUNCH_CHECK();
@@ -907,7 +1191,8 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
                                                       c->sk_row0, c->sk_col0}));
         LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
+    if (host) hipLaunchKernelGGL(k_hl_err, dim3((B + 63) / 64), dim3(64), 0, s, h->err_h, h->flags, err, B);
+    else hipLaunchKernelGGL(k_collect_err, dim3((B + 63) / 64), dim3(64), 0, s, c->d_state, err, B);
     LAUNCH_CHECK();
     return 0;
 }

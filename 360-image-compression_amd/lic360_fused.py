@@ -121,6 +121,11 @@ class FusedCodec(object):
             raise Lic360Error("arithmetic decoder fault (corrupt stream?): %s" % self.err[:b].cpu().tolist())
         return out
 
+    def set_coder(self, mode):
+        """where the serial coder phases run: "device" (one wave per image), "host" (one host thread per image, <= 64 images per call), "auto"
+        (default: host for calls of at most 16 images -- the latency regime)"""
+        _chk(_lib.lic360_codec_set_coder(self._h, {"device": 0, "host": 1, "auto": 2}[mode]))
+
     # ---- dead-cone skip (csrc/need.h): statistics and test hooks ---------------------------------------
     def skip_active(self):
         """0: this codec computes every output (generic kernels or LIC360_NOSKIP); 1: the encode-order launches skip dead (tile, group block)

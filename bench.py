@@ -362,9 +362,24 @@ def run_rank(args):
             if not n:
                 continue
             mb = last_mb.get(id(c))
-            ok = ok and bool(torch.equal(c.code_out[:n], cd * mk)) and int(c.err[:n].abs().sum().item()) == 0
+            flags = {"code": bool(torch.equal(c.code_out[:n], cd * mk)), "err": int(c.err[:n].abs().sum().item()) == 0}
             if imp:                                                          # ... and the mask the device derived from the decoded map is the encoder's
-                ok = ok and bool(torch.equal(ic.levels_out[:n], lv)) and int(ic.err[:n].abs().sum().item()) == 0 and mb is not None and bool(torch.equal(mb[:n], mk))
+                flags.update(levels=bool(torch.equal(ic.levels_out[:n], lv)), imp_err=int(ic.err[:n].abs().sum().item()) == 0,
+                             mask=mb is not None and bool(torch.equal(mb[:n], mk)))
+            if not all(flags.values()):
+                bad = (c.code_out[:n] != cd * mk).flatten(1).any(1).nonzero().flatten().tolist()
+                sys.stderr.write("[bench] round trip NOT exact on rank %d, sub-batch of %d images: %s; images with wrong symbols: %s\n" % (rank, n, flags, bad[:16]))
+                # which direction: the bitstreams of the failed pass against a fresh encode of the same sub-batch alone on the GPU, then a decode alone
+                torch.cuda.synchronize(dev)
+                nb0, by0 = c.nbytes[:n].clone(), c.bytes[:n].clone()
+                c.encode_async(cd, mk)
+                torch.cuda.synchronize(dev)
+                same = [bool(nb0[i] == c.nbytes[i]) and bool(torch.equal(by0[i, :int(nb0[i])], c.bytes[i, :int(nb0[i])])) for i in range(n)]
+                c.decode_async(mk, n)
+                torch.cuda.synchronize(dev)
+                again = (c.code_out[:n] != cd * mk).flatten(1).any(1).nonzero().flatten().tolist()
+                sys.stderr.write("[bench]   images whose bitstream differs from a fresh encode: %s; wrong after a decode alone: %s\n" % ([i for i in range(n) if not same[i]][:16], again[:16]))
+            ok = ok and all(flags.values())
         return ok
 
     say = progress if rank == 0 else (lambda m: None)

@@ -89,8 +89,10 @@ def test_cast_entropy_parameter():
                                           (4, 66, 10, 16, 22),     # two row segments, the last (4 rows) packed
                                           (6, 28, 40, 24, 23),     # 8 | images: the decode kernel tape-packs its samples (tapes of 3; round 5)
                                           (6, 50, 12, 40, 24)])    # ... tapes of 5, windows cut between tasks
-def test_fused_codec_matches_oracle(G, H, W, B, seed):
-    """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode."""
+@pytest.mark.parametrize("coder", ["device", "host"])
+def test_fused_codec_matches_oracle(G, H, W, B, seed, coder):
+    """Device-resident codec: byte-identical bitstreams to the oracle pipeline, exact decode -- with the serial coder phases on the GPU (one wave per
+    image) and on host threads (the reference's own place for them, coder.cpp:70-113: records D2H / per-plane tables through pinned memory)."""
     from lic360_fused import FusedCodec
     rng = np.random.default_rng(seed)
     layers = rc.make_main_params(2000 + seed, G)
@@ -101,6 +103,7 @@ def test_fused_codec_matches_oracle(G, H, W, B, seed):
         mask[1] = 0.0                      # one fully masked image -> bare terminator byte
     fc = FusedCodec(G, H, W, max_batch=max(4, B))
     fc.load_layers(layers)
+    fc.set_coder(coder)
     streams = fc.encode(dev(code), dev(mask))
     for i in range(B):
         assert streams[i] == rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G), "image %d" % i
@@ -220,9 +223,10 @@ def test_latent_decode_gated_behind_the_map_decode(G, MH, MW, B, seed):
     assert np.array_equal(out.cpu().numpy(), code * mask)
 
 
-def test_fused_codec_corrupt_stream_is_reported_not_fatal():
+@pytest.mark.parametrize("coder", ["device", "host"])
+def test_fused_codec_corrupt_stream_is_reported_not_fatal(coder):
     """A truncated / damaged bitstream must end in an error (or a wrong-but-finite decode), never in a hang or a fault:
-    the device decoder reads zeros past the end of a stream, like the reference's BitInputStream."""
+    the decoders (device wave or host thread) read zeros past the end of a stream, like the reference's BitInputStream."""
     from lic360_fused import FusedCodec, Lic360Error
     G, H, W, B = 6, 8, 12, 2
     rng = np.random.default_rng(41)
@@ -232,6 +236,7 @@ def test_fused_codec_corrupt_stream_is_reported_not_fatal():
     mask = np.concatenate([it[1] for it in items], 0)
     fc = FusedCodec(G, H, W, max_batch=B)
     fc.load_layers(layers)
+    fc.set_coder(coder)
     good = fc.encode(dev(code), dev(mask))
     damaged = [good[0][:len(good[0]) // 2], bytes(b ^ 0x5A for b in good[1])]
     try:
