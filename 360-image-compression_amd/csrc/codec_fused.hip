@@ -66,11 +66,11 @@ struct lic360_codec {
     bool stats_on = false;
     // Host leg of the arithmetic coder (round 6; the reference's own division of labour: extension/coder.cpp:70-113 runs on the CPU).  One wave per image
     // is the slowest possible coder -- 27.6 ms per image to encode, ~170 us per plane to decode -- and only hides behind other images' convolutions; a
-    // host thread does 21 / 29 ns per symbol.  With few images per call (<= coder_auto_max) the serial phases therefore run on host threads:
+    // host thread does 21 / 29 ns per symbol.  With few images per call (<= coder_auto_max = 8) the serial phases therefore run on host threads:
     // encode -- records D2H, one thread per image, bitstreams H2D; decode -- per plane the packed tables go to pinned memory, one persistent thread per
     // image decodes its symbols, a GPU kernel waits for them on polled flags (no API call, no stream synchronisation per plane).
     int coder_mode = 2;                        // 0 device, 1 host, 2 auto (host when B <= coder_auto_max); LIC360_HOST_CODER=0|1 overrides at create
-    int coder_auto_max = 16;
+    int coder_auto_max = 8;                    // (16 images per stream on three streams lose: config 4 as written 52 -> 36 Mpixel/s, config 5 47 -> 18 -- every plane then waits for its slowest host thread while the GPU coder of one stream hides behind the other streams' convolutions)
     struct HostLeg *hl = nullptr;
     // optional per-kernel-class timing (bench.py's instrumented pass; off in the timed region): HIP event pairs around
     // every launch of a class, recorded on the launch stream
@@ -722,7 +722,7 @@ static int hl_get(lic360_codec *c, int B, long cap, HostLeg **out) {
     if (!h) {
         h = new HostLeg();
         c->hl = h;
-        h->maxB = std::max(B, std::min(c->maxB, HL_MAXB)); h->cap = cap; h->nsym = nsym; h->tab_pitch = c->tab_pitch;
+        h->maxB = std::max(B, std::min(c->maxB, c->coder_auto_max)); h->cap = cap; h->nsym = nsym; h->tab_pitch = c->tab_pitch;
         int rc = hl_alloc(&h->rec_h, (size_t)h->maxB * nsym) | hl_alloc(&h->bytes_h, (size_t)h->maxB * cap) | hl_alloc(&h->nbytes_h, h->maxB) |
                  hl_alloc(&h->err_h, h->maxB) | hl_alloc(&h->tab_h, (size_t)h->maxB * h->tab_pitch * 8) | hl_alloc(&h->sym_h, (size_t)h->maxB * h->tab_pitch) |
                  hl_alloc(&h->flags, HL_FB + HL_MAXB) | dmalloc(&h->d_ctr, 1);
@@ -1024,7 +1024,7 @@ LIC360_API int lic360_codec_set_layer(void *stream, lic360_codec *c, int layer, 
 static bool coder_on_host(const lic360_codec *c, int B) {
     return c->coder_mode == 1 ? B <= HL_MAXB : (c->coder_mode == 2 && B <= c->coder_auto_max);
 }
-// 0: the serial coder phases run on the GPU (one wave per image), 1: on host threads (B <= 64), 2: auto -- host for calls of at most 16 images (the
+// 0: the serial coder phases run on the GPU (one wave per image), 1: on host threads (B <= 64), 2: auto -- host for calls of at most 8 images (the
 // latency regime: the GPU coder only pays where other images' convolutions hide it)
 LIC360_API int lic360_codec_set_coder(lic360_codec *c, int mode) {
     ARG_CHECK(c && mode >= 0 && mode <= 2);

@@ -9,6 +9,7 @@
 // chains whose own outputs are dead, or with zero weights.
 #include "common.h"
 #include "need.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ need maps
 // one workgroup per image; layer l is computed from layer l + 1 of the same image, a workgroup barrier between the layers
@@ -250,6 +251,39 @@ __global__ __launch_bounds__(128) void k_dc_tasks(const DcListArgs a) {
     }
 }
 
+// Balance the eight lists of a launch.  Each XCD owns the samples n = xcd (mod 8) -- their bands stay in that XCD's L2 from layer to layer -- and with the
+// dead-cone hulls the lists' work differs with the images' masks: a launch waits for its most loaded XCD, +3.9 % over the mean on SURVEY 8d's masks
+// (12 % on the last layer; tools/list_balance.py).  A record carries its absolute sample index, so any XCD can run it: the lightest records (the tail: lists
+// are heaviest block first) of the most loaded list move to the least loaded one while that lowers the pair's maximum.  Work of a record = the steps of its
+// block's longest chain.  One workgroup per (plane, layer); the moved records (a few per cent) read their bands through another XCD's L2.
+__global__ __launch_bounds__(64) void k_dc_balance(const DcListArgs a) {
+    __shared__ int w[8], n[8];
+    const int p = blockIdx.x, l = a.l0 + blockIdx.y, tid = threadIdx.x;
+    const long li = ((long)l * a.P + p) * 8;
+    auto steps = [&](unsigned x) { const int g0 = (int)(x & 127u), s = g0 + 2 + 4 + 1; return s < a.G ? s : a.G; };
+    if (tid < 8) {
+        const int c = a.cnt[li + tid];
+        const uint4 *r = a.list + (li + tid) * a.cap;
+        int acc = 0;
+        for (int i = 0; i < c; ++i) acc += steps(r[i].x);
+        n[tid] = c; w[tid] = acc;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int it = 0; it < 8 * a.cap; ++it) {
+        int hx = 0, lx = 0;
+        for (int x = 1; x < 8; ++x) { if (w[x] > w[hx]) hx = x; if (w[x] < w[lx]) lx = x; }
+        if (hx == lx || n[hx] == 0 || n[lx] >= a.cap) break;
+        const uint4 rec = a.list[(li + hx) * a.cap + n[hx] - 1];
+        const int s = steps(rec.x);
+        if (w[lx] + s >= w[hx]) break;                                      // the move would not lower the pair's maximum
+        a.list[(li + lx) * a.cap + n[lx]] = rec;
+        ++n[lx]; --n[hx];
+        w[lx] += s; w[hx] -= s;
+    }
+    for (int x = 0; x < 8; ++x) a.cnt[li + x] = n[x];
+}
+
 // layers 1..11 (cin = 4: hidden and last layers; the first layer keeps its full task list)
 int lic360_dc_lists_build(void *stream, const signed char *need_d, int B, int G, int H, int W, const lic360_dc_lists &l, unsigned long long *stats) {
     ARG_CHECK(need_d && l.list && l.cnt && B > 0 && B % 8 == 0 && B / 8 <= DCL_MAXM && H <= 64 && G <= 3 * DCL_MAXB && l.P == H + W + G - 2);
@@ -258,6 +292,11 @@ int lic360_dc_lists_build(void *stream, const signed char *need_d, int B, int G,
     a.need_d = need_d; a.list = l.list; a.cnt = l.cnt; a.stats = stats; a.cap = l.cap; a.l0 = 1; a.npb = B; a.G = G; a.H = H; a.W = W; a.P = l.P;
     hipLaunchKernelGGL(k_dc_tasks, dim3(8, l.P, NEED_LAYERS - 1), dim3(128), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK();
+    static const bool balance = !getenv("LIC360_NOBALANCE");                // (A/B switch of the XCD balancing pass)
+    if (balance) {
+        hipLaunchKernelGGL(k_dc_balance, dim3(l.P, NEED_LAYERS - 1), dim3(64), 0, (hipStream_t)stream, a);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 

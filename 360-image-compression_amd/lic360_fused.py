@@ -123,7 +123,7 @@ class FusedCodec(object):
 
     def set_coder(self, mode):
         """where the serial coder phases run: "device" (one wave per image), "host" (one host thread per image, <= 64 images per call), "auto"
-        (default: host for calls of at most 16 images -- the latency regime)"""
+        (default: host for calls of at most 8 images -- the latency regime)"""
         _chk(_lib.lic360_codec_set_coder(self._h, {"device": 0, "host": 1, "auto": 2}[mode]))
 
     # ---- dead-cone skip (csrc/need.h): statistics and test hooks ---------------------------------------

@@ -367,7 +367,7 @@ int lic360_devcoder_decode(void *stream, const int *tables, int ncode, const flo
 /* Where the serial arithmetic-coder phases of the fused latent codec run.  The reference runs its coder on the CPU (extension/coder.cpp:70-113, called per
  * plane from test/lic360_demo.py:139-140,234); the fused codec keeps it on the GPU (one wave per image) where many images per call hide it, and hands it
  * to host threads -- records D2H / per-plane tables through pinned memory, polled flags -- when a call holds few images.  mode 0: device, 1: host
- * (<= 64 images per call), 2 (default): host for calls of at most 16 images.  LIC360_HOST_CODER=0|1 sets the mode at create.  Bitstreams are identical. */
+ * (<= 64 images per call), 2 (default): host for calls of at most 8 images.  LIC360_HOST_CODER=0|1 sets the mode at create.  Bitstreams are identical. */
 int lic360_codec_set_coder(lic360_codec *codec, int mode);
 
 /* ---- dead-cone skip of the fused latent codec (round 6; csrc/need.h) -------------------------------------------------------------

@@ -175,7 +175,7 @@ def test_task_lists_cover_the_live_cells_exactly_once(G, H, W, B):
             for x in range(8):
                 for r in rec[l, p, x, :cnt[l, p, x]]:
                     g0, packed, n = int(r[0] & 127), int((r[0] >> 7) & 7), int(r[0] >> 10)
-                    assert n % 8 == x and n < 3 * B and g0 % 3 == 0
+                    assert n < 3 * B and g0 % 3 == 0                            # (n % 8 is the record's HOME XCD; the balancing pass may have moved it to list x)
                     pieces = []
                     if packed == 0:
                         pieces.append((n, 0, H - 1, None))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the rocprofv3 evidence behind profiles/rNN_* -- kernel stats of the default bench,
 # kernel stats of the encode / decode / importance-map probes alone on the GPU, and the FETCH_SIZE / WRITE_SIZE passes (each counter in its own run).
-# usage: tools/collect_profiles.sh r05      -> gpurun_out/prof_r05/...   (progress lines on stdout: the run takes ~12 minutes)
+# usage: tools/collect_profiles.sh r06      -> gpurun_out/prof_r06/...   (progress lines on stdout: the run takes ~12 minutes)
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
