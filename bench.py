@@ -63,8 +63,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=144, help="images per GPU per step: 144 resident images (3 sub-batches of 48) keep the "
-                    "decode wavefront wide enough to fill 256 CUs (BASELINE.json configs[3] is the 8-per-GPU form: see `config4`)")
+    ap.add_argument("--batch", type=int, default=192, help="images per GPU per step: 192 resident images = 3 sub-batches of 64 (rounds 1-5: 144 = 3 x 48; "
+                    "side figure `batch144_mpixel_s`).  64 images per sub-batch are 8 per (net, XCD) list -- exactly one packing chunk of the dead-cone task "
+                    "lists (csrc/need.h); measured 144 / 192 / 240 / 288 / 384: 61.3 / 62.7 / 62.3 / 62.3 / 62.7 Mpixel/s on one box.  "
+                    "(BASELINE.json configs[3] is the 8-per-GPU form: see `config4`)")
     ap.add_argument("--streams", type=int, default=3, help="the per-GPU batch is split over this many HIP streams so that one "
                     "sub-batch's serial arithmetic-coder phases overlap the other's convolutions")
     ap.add_argument("--imp-streams", type=int, default=1, help="1: the importance-map codecs run on HIP streams of their own; 0: on their sub-batch's stream")
@@ -398,6 +400,14 @@ def run_rank(args):
 
     say("timed region done: %.1f ms per step" % (dt / args.steps * 1e3))
     extras = {}
+    if not args.no_extras and B > 144 and all(sz >= 48 for sz in sizes) and ns == 3:
+        # the per-GPU batch of rounds 1-5 (144 = 3 x 48 images) through the same codecs: what the larger sub-batches add
+        c48, m48, l48 = [c[:48] for c in codes], [m[:48] for m in masks], [l[:48] for l in levels]
+        run(c48, m48, l48)
+        dt48 = shard.timed(lambda: run(c48, m48, l48), args.steps, dev)
+        ok = ok and exact(c48, m48, l48)
+        extras["batch144"] = {"value": world * 144 * args.steps * PIXELS / dt48 / 1e6, "unit": "Mpixel/s", "ms_per_step": dt48 / args.steps * 1e3,
+                              "note": "144 images per GPU (3 sub-batches of 48), the per-GPU batch of rounds 1-5"}
     if not args.no_extras and args.masks != "iid":
         # the same step on the masks of rounds 1-5 (every map cell drawn independently): nothing for the dead-cone skip to find -- the adversarial case
         ci, mi, li = synth_latents(B, seed0=1000 * rank, kind="iid")
@@ -523,6 +533,8 @@ def run_rank(args):
             flat["value_per_calib_mfma_tflop"] = out["value"] / calib["calib_mfma_tflops"]
         if "iid_masks" in extras:
             flat["iid_masks_mpixel_s"] = extras["iid_masks"]["value"]
+        if "batch144" in extras:
+            flat["batch144_mpixel_s"] = extras["batch144"]["value"]
         if "latent_stream_only" in extras:
             flat["latent_only_mpixel_s"] = extras["latent_stream_only"]["value"]
         if "config4" in extras:

@@ -10,7 +10,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/bench -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 echo bench done
-export PB=48
+export PB=64
 rocprofv3 --kernel-trace --stats -d $O/dc -o p --output-format csv -- python3 $R/tools/dc_probe.py > $O/dc_probe.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/ec -o p --output-format csv -- python3 $R/tools/ec_probe.py > $O/ec_probe.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/imp -o p --output-format csv -- python3 $R/tools/imp_probe.py > $O/imp_probe.txt 2>&1
@@ -25,7 +25,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 echo pmc done
 cd $R
-python3 tools/pmc_traffic.py $O/pmc_traffic.json 48 $O/dc_FETCH_SIZE/p_counter_collection.csv $O/dc_WRITE_SIZE/p_counter_collection.csv \
+python3 tools/pmc_traffic.py $O/pmc_traffic.json 64 $O/dc_FETCH_SIZE/p_counter_collection.csv $O/dc_WRITE_SIZE/p_counter_collection.csv \
     $O/ec_FETCH_SIZE/p_counter_collection.csv $O/ec_WRITE_SIZE/p_counter_collection.csv \
     $O/imp_FETCH_SIZE/p_counter_collection.csv $O/imp_WRITE_SIZE/p_counter_collection.csv
 python3 tools/stream_ops_bench.py > $O/stream_ops.json
