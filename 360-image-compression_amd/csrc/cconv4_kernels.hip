@@ -22,7 +22,7 @@
 //
 // Decode order only (cconv4v6_dc.inc): persistent workgroups of 12 waves = 3 adjacent groups (adjacent anti-diagonals of the
 // current plane) of one sample.  Encode order runs on the 16x16x4 kernels of cconv16_kernels.hip; the 4x4x1 encode kernels and
-// the LDS-DMA generation of the decode kernel were retired in round 5 (tools/experiments/r05_pruned_kernel_generations.patch).
+// the LDS-DMA generation of the decode kernel were retired in round 5 (git show c0e481c).
 #include "common.h"
 #include "conv_plan.h"
 

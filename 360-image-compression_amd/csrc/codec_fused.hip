@@ -1436,7 +1436,7 @@ LIC360_API int lic360_impcodec_create(int h, int w, int hidden_channels, int nsy
     rc |= dmalloc(&c->e_x0, B * HW);
     for (int i = 0; i < 3; ++i) rc |= dmalloc(&c->e_buf[i], B * CE * HW);
     rc |= dmalloc(&c->e_rec, B * HW);
-    // 144-channel layers on the leaf-resident 16x16x4 kernels (LIC360_IMP144=0 keeps the generic kernels: A/B runs)
+    // 144-channel layers on the leaf-resident 16x16x4 kernels (other widths keep the generic kernels)
     c->use144 = lic360_conv144_supported(c->plan[1]) && lic360_conv144_supported(c->plan[2]);
     if (c->use144) {
         if (lic360_ec144_layout(h, w, &c->e_hp, &c->e_wp) || lic360_dc144_layout(h, w, &c->sk_rows, &c->sk_pitch)) return 1;

@@ -2,7 +2,7 @@
 // hand-written for gfx950: the tile loader reads the SPHERE APRON BY INDEX (no padded copy, no SpherePad launch), the epilogue applies
 // bias + PReLU + the block's residual add, and the SphereTrim that follows every such convolution becomes the output window (cells outside
 // it are simply not computed).  Replaces, per layer, nn.Conv2d + SpherePad + nn.PReLU + SphereTrim (+ the residual add) of
-// /root/reference/test/model_zoo.py:45-62 (ResidualBlockV2), :8-23 (ResidualBlock.conv2), :64-94 (ResidualBlockDown.conv2),
+// test/model_zoo.py:45-62 of the reference (ResidualBlockV2), :8-23 (ResidualBlock.conv2), :64-94 (ResidualBlockDown.conv2),
 // :144-169 (ResidualBlockUp.conv1 / conv2); apron rule: extension/sphere_pad_cuda.cu:48-65.
 //
 // Arithmetic: fp32 throughout, v_mfma_f32_16x16x4_f32 (bit for bit a k-ordered fmaf chain of 4 terms); the summation order over

@@ -80,8 +80,8 @@ def parse_args():
 
 
 def split_for_streams(n, ns):
-    """sizes of the sub-batches of n images on ns streams: multiples of 16 where the list is long enough (the decode kernel takes two
-    samples per wave on the short corner diagonals when 16 divides the images per net), the remainder on the last stream; a list
+    """sizes of the sub-batches of n images on ns streams: multiples of 16 where the list is long enough (the decode kernel packs the samples of an
+    XCD's list -- tapes / dead-cone task records -- when 8 divides the images per net; 16 images make lists of two), the remainder on the last stream; a list
     shorter than 16 images stays on one stream (it is latency-bound: the per-plane chain is the same for 1 or 8 images)"""
     if n < 16:
         return [n] + [0] * (ns - 1)

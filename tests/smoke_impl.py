@@ -18,8 +18,11 @@ def run():
     fc = FusedCodec(G, H, W, max_batch=B)
     fc.load_layers(layers)
     d = lambda a: torch.from_numpy(a).to("cuda:0")
-    streams = fc.encode(d(code), d(mask))
-    for i in range(B):
-        assert streams[i] == rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G), "bitstream %d differs from the oracle" % i
-    out = fc.decode(streams, d(mask)).cpu().numpy()
-    assert np.array_equal(out, code * mask), "decoded symbols differ"
+    ref = [rc.encode_main(code[i:i + 1], mask[i:i + 1], layers, G) for i in range(B)]
+    for coder in ("device", "host"):                                    # the serial coder on the GPU (one wave per image) and on host threads (small calls)
+        fc.set_coder(coder)
+        streams = fc.encode(d(code), d(mask))
+        for i in range(B):
+            assert streams[i] == ref[i], "bitstream %d differs from the oracle (coder on the %s)" % (i, coder)
+        out = fc.decode(streams, d(mask)).cpu().numpy()
+        assert np.array_equal(out, code * mask), "decoded symbols differ (coder on the %s)" % coder

@@ -88,7 +88,7 @@ def test_hip_drivers_reproduce_the_reference_drivers(tmp_path, path):
     assert np.array_equal(fic.decode([imp]).cpu().numpy(), levels)
     if H >= 28:
         # the 64-row golden as a batch of 16 copies: more than 128 three-group tasks per launch, so the decode kernel leaves its latency mode and
-        # runs its throughput schedule -- full-lane diagonals, two samples per task on the corner diagonals (16 | samples per net)
+        # runs its throughput schedule -- full-lane diagonals, the samples of an XCD's list packed end to end over the lanes (8 | samples per net; 16 images: the dead-cone task records)
         fcb = FusedCodec(G, H, W, max_batch=16)
         fcb.load_layers(layers)
         rep = lambda a: np.ascontiguousarray(np.repeat(a, 16, 0))
