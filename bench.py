@@ -83,6 +83,11 @@ def split_for_streams(n, ns):
     """sizes of the sub-batches of n images on ns streams: multiples of 16 where the list is long enough (the decode kernel packs the samples of an
     XCD's list -- tapes / dead-cone task records -- when 8 divides the images per net; 16 images make lists of two), the remainder on the last stream; a list
     shorter than 16 images stays on one stream (it is latency-bound: the per-plane chain is the same for 1 or 8 images)"""
+    exp = os.environ.get("LIC360_SPLIT_SMALL")                           # experiment: "4,4,0" = how a list shorter than 16 images is split
+    if n < 16 and exp:
+        sz = [int(v) for v in exp.split(",")][:ns]
+        if sum(sz) == n:
+            return sz + [0] * (ns - len(sz))
     if n < 16:
         return [n] + [0] * (ns - 1)
     blocks, rem = divmod(n, 16)
