@@ -35,6 +35,7 @@
 #include "conv_plan.h"
 #include "cconv_tree.h"
 #include "gmm_tables.h"
+#include "need.h"
 
 #define C16_SLOTS 28                       // weight slots per lane class and step (cin = 4: 25 taps; cin = 1: 4 sub-quads x 7 taps)
 #define C16_TH 4                           // tile rows
@@ -1075,7 +1076,7 @@ static int c16_fill_args(C16Args &a, const lic360_conv_plan *p, int h, int w, in
     a.ntiles = a.ntx * ((h + C16_TH - 1) / C16_TH);
     a.n_chunks = (a.ntiles + tpt - 1) / tpt;
     a.NS = conv16_nsteps_max(p);
-    a.gbk = 16;                                                             // task-order block size (blocks of 4 .. all measured: DESIGN 4.1 a)
+    a.gbk = lic360_ec_gbk();                                                // task-order block size: 16 (blocks of 4 .. all measured: DESIGN 4.1 a)
     a.code = a.mask = nullptr; a.pidx = a.plane_start = nullptr; a.rec = nullptr;
     a.list = a.cnt = nullptr; a.list_cap = 0;
     return 0;

@@ -45,6 +45,14 @@ __host__ __device__ inline int dcl_wave_pieces(const int *lo, const int *hi, int
     return nwin;
 }
 
+// units per block of the encode kernels' task order (c16_fill_args and the list builder must agree): 16 measured best without lists (DESIGN 4.1 a);
+// LIC360_EC_GBK overrides it for A/B runs
+#include <cstdlib>
+static inline int lic360_ec_gbk(void) {
+    static const int v = [] { const char *e = getenv("LIC360_EC_GBK"); const int x = e ? atoi(e) : 0; return x > 0 && x <= 4096 ? x : 16; }();
+    return v;
+}
+
 // internal entries (hidden visibility)
 // need [B][12][H][W] and its diagonal-major copy need_d [B][12][H+W-1][H] (cell (y, x) at [(y + x) * H + y]; cells outside the image: -1),
 // tile maxima tmax [B][12][nty][ntx] over the encode kernels' 4 x 16 tiles; all int8

@@ -118,7 +118,7 @@ int lic360_ec_lists_build(void *stream, const signed char *tmax, int B, int G, i
     ARG_CHECK(tmax && l.list && l.cnt && B > 0);
     const int ntx = (W + 15) / 16, ntiles = ntx * ((H + 3) / 4);
     EcListArgs a;
-    a.tmax = tmax; a.list = l.list; a.cnt = l.cnt; a.stats = stats; a.cap = l.cap; a.npb = B; a.ntiles = ntiles; a.gbk = 16;
+    a.tmax = tmax; a.list = l.list; a.cnt = l.cnt; a.stats = stats; a.cap = l.cap; a.npb = B; a.ntiles = ntiles; a.gbk = lic360_ec_gbk();
     a.l0 = 1; a.N = 3 * B; a.gpb = 4; a.tpt = 4; a.n_chunks = (ntiles + 3) / 4; a.n_gb = (G + 3) / 4;
     ARG_CHECK(((a.N + 7) / 8) * a.n_chunks * a.n_gb <= l.cap && ((a.N + 7) / 8) * a.n_chunks * a.n_gb < (1 << 28));
     hipLaunchKernelGGL(k_ec_tasks, dim3(8, 10), dim3(256), 0, (hipStream_t)stream, a);
