@@ -17,7 +17,8 @@
 #define NEED_STAT_G 64                     // statistics rows: [layer][group] stored cells (decode order), [layer][group block] live tiles (encode order)
 
 // ---- decode order: per (layer, plane, XCD) lists of task records for cconv4v6_dc.inc's LIST kernels.
-// record = uint4: x = g0 | packed << 7 | n << 10   (packed 4: up to three pieces y / z / w, sample n + 8 k each; packed 0: sample n, whole diagonals)
+// record = uint4: x = g0 | packed << 7 | n << 10   (packed 4: up to three pieces y / z / w, sample n + 8 k each; packed 0: sample n, whole diagonals);
+//                 bits 22..24 of y: which of the block's three groups g0, g0 + 1, g0 + 2 are live on some row of the record (the others' wave sets idle)
 // piece  = k | slo << 3 | shi << 9 | a0 << 15 | 1 << 21   (rows slo..shi of sample k of the chunk in lanes a0.., as the tape's pieces)
 #define DCL_CHUNK 8                        // samples per packing chunk (k has 3 bits)
 

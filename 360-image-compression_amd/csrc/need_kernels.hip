@@ -146,6 +146,7 @@ struct DcListArgs {
 };
 __global__ __launch_bounds__(128) void k_dc_tasks(const DcListArgs a) {
     __shared__ short wlo[DCL_MAXB][DCL_MAXM], whi[DCL_MAXB][DCL_MAXM];
+    __shared__ unsigned char wgm[DCL_MAXB][DCL_MAXM];                     // which of the block's three groups have a live row (of that image, on this plane)
     __shared__ int nrec[DCL_MAXB], plain[DCL_MAXB], offs[DCL_MAXB + 1], s_stat[DCL_MAXB * 3];
     const int xcd = blockIdx.x, p = blockIdx.y, l = a.l0 + blockIdx.z, tid = threadIdx.x;
     const int G = a.G, H = a.H, W = a.W, S = H + W - 1, m = a.npb / 8;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(128) void k_dc_tasks(const DcListArgs a) {
     if (tid < DCL_MAXB * 3) s_stat[tid] = 0;
     for (int job = tid; job < n_gbv * m; job += 128) {
         const int j = job / m, k = job - j * m, img = xcd + 8 * k, g0 = (n_gb - 1 - j) * 3, s0 = p - g0;
-        int lo = 1 << 20, hi = -1;
+        int lo = 1 << 20, hi = -1, gm = 0;
         for (int q = 0; q < 3; ++q) {
             const int g = g0 + q, sq = s0 - q;
             if (g >= G || sq < 0 || sq >= S) continue;
@@ -176,9 +177,11 @@ __global__ __launch_bounds__(128) void k_dc_tasks(const DcListArgs a) {
             while (row[z] < g) --z;
             lo = y < lo ? y : lo;
             hi = z > hi ? z : hi;
+            gm |= 1 << q;
         }
         wlo[j][k] = (short)(hi < 0 ? 0 : lo);
         whi[j][k] = (short)hi;
+        wgm[j][k] = (unsigned char)gm;
     }
     __syncthreads();
     // pass 1 (one thread per block): records of one net's list, packed against plain
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(128) void k_dc_tasks(const DcListArgs a) {
             dlo[q] = ok ? (sq >= W ? sq - W + 1 : 0) : 1;
             dhi[q] = ok ? (sq < H ? sq : H - 1) : 0;
         }
-        auto count = [&](int rlo, int rhi) {
-            for (int q = 0; q < 3; ++q) { const int u = rlo > dlo[q] ? rlo : dlo[q], v = rhi < dhi[q] ? rhi : dhi[q]; if (v >= u) cells[q] += v - u + 1; }
+        auto count = [&](int rlo, int rhi, int gm) {
+            for (int q = 0; q < 3; ++q) { const int u = rlo > dlo[q] ? rlo : dlo[q], v = rhi < dhi[q] ? rhi : dhi[q]; if (v >= u && (gm >> q & 1)) cells[q] += v - u + 1; }
         };
         for (int c0 = 0; c0 < m; c0 += DCL_CHUNK) {
             const int c = m - c0 < DCL_CHUNK ? m - c0 : DCL_CHUNK, nb = xcd + 8 * (net * m + c0);
@@ -226,17 +229,20 @@ __global__ __launch_bounds__(128) void k_dc_tasks(const DcListArgs a) {
             if (plain[j]) {
                 for (int k = 0; k < c; ++k)
                     if (hi[k] >= lo[k]) {
-                        if (o < a.cap) out[o] = make_uint4((unsigned)g0 | (unsigned)(nb + 8 * k) << 10, 0u, 0u, 0u);
+                        const unsigned gm = wgm[j][c0 + k];
+                        if (o < a.cap) out[o] = make_uint4((unsigned)g0 | (unsigned)(nb + 8 * k) << 10, gm << 22, 0u, 0u);
                         ++o;
-                        count(0, H - 1);
+                        count(0, H - 1, (int)gm);
                     }
             } else {
                 int k = 0, slo = lo[0];
                 unsigned pc[3];
                 while (k < c && dcl_wave_pieces(lo, hi, H, c, k, slo, pc) > 0) {
-                    if (o < a.cap) out[o] = make_uint4((unsigned)g0 | 4u << 7 | (unsigned)nb << 10, pc[0], pc[1], pc[2]);
+                    unsigned gm = 0u;                                       // groups live in ANY of the record's samples (bits 22..24 of the first piece word)
+                    for (int i = 0; i < 3; ++i) if (pc[i]) gm |= wgm[j][c0 + (pc[i] & 7)];
+                    if (o < a.cap) out[o] = make_uint4((unsigned)g0 | 4u << 7 | (unsigned)nb << 10, pc[0] | gm << 22, pc[1], pc[2]);
                     ++o;
-                    for (int i = 0; i < 3; ++i) if (pc[i]) count((pc[i] >> 3) & 63, (pc[i] >> 9) & 63);
+                    for (int i = 0; i < 3; ++i) if (pc[i]) count((pc[i] >> 3) & 63, (pc[i] >> 9) & 63, (int)gm);
                 }
             }
         }

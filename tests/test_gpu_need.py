@@ -175,6 +175,8 @@ def test_task_lists_cover_the_live_cells_exactly_once(G, H, W, B):
             for x in range(8):
                 for r in rec[l, p, x, :cnt[l, p, x]]:
                     g0, packed, n = int(r[0] & 127), int((r[0] >> 7) & 7), int(r[0] >> 10)
+                    gm = int(r[1] >> 22) & 7                                    # the groups of the block that the record computes at all
+                    assert gm
                     assert n < 3 * B and g0 % 3 == 0                            # (n % 8 is the record's HOME XCD; the balancing pass may have moved it to list x)
                     pieces = []
                     if packed == 0:
@@ -199,7 +201,7 @@ def test_task_lists_cover_the_live_cells_exactly_once(G, H, W, B):
                     for smp, slo, shi, _ in pieces:
                         for q in range(3):
                             g, s = g0 + q, p - g0 - q
-                            if g >= G or s < 0 or s >= S:
+                            if g >= G or s < 0 or s >= S or not gm >> q & 1:
                                 continue
                             ys = np.arange(max(slo, s - W + 1, 0), min(shi, s, H - 1) + 1)
                             stored[l, smp, g, ys, s - ys] += 1
