@@ -320,3 +320,20 @@ LIC360_API int lic360_need_maps(void *stream, const float *mask, int B, int G, i
     (void)hipFree(dd); (void)hipFree(tm);
     return rc;
 }
+
+// Host-only view of the list packing (no GPU work): the waves into which dcl_wave_pieces lays the row windows lo[k]..hi[k] (k < c <= 8; hi < lo: sample k
+// has no live row) of ONE chunk of samples on an image of h rows; pieces[3 w + i] = piece i of wave w (k | slo << 3 | shi << 9 | a0 << 15 | 1 << 21, 0 = none),
+// room for 3 * 2 * c words; *n_waves = waves used.  For tests of the packing rules on the CPU (tests/test_dcl_pack.py).
+LIC360_API int lic360_dcl_pack_layout(int h, int c, const int *lo, const int *hi, unsigned *pieces, int *n_waves) {
+    ARG_CHECK(h > 0 && h <= 64 && c > 0 && c <= DCL_CHUNK && lo && hi && pieces && n_waves);
+    for (int k = 0; k < c; ++k) ARG_CHECK(hi[k] < lo[k] || (lo[k] >= 0 && hi[k] < h));
+    int k = 0, slo = lo[0], nw = 0;
+    unsigned pc[3];
+    while (k < c && dcl_wave_pieces(lo, hi, h, c, k, slo, pc) > 0) {
+        ARG_CHECK(nw < 2 * c);
+        for (int i = 0; i < 3; ++i) pieces[3 * nw + i] = pc[i];
+        ++nw;
+    }
+    *n_waves = nw;
+    return 0;
+}

@@ -376,6 +376,10 @@ int lic360_codec_set_coder(lic360_codec *codec, int mode);
  * output some coded symbol reads (-1: none), need_11 = the mask's highest coded group, need_l = min(G - 1, 5 x 5 dilation of need_{l+1} + dy + dx).
  * Bitstreams and decoded symbols are unchanged.  lic360_need_maps: masks [b, g, h, w] -> need [b][12][h][w] int8 (device), the kernel the codec runs. */
 int lic360_need_maps(void *stream, const float *mask, int b, int g, int h, int w, signed char *need_out);
+/* Host-only (no GPU work): how the decode-order task lists pack the live row windows lo[k]..hi[k] (k < c <= 8 samples of one chunk; hi < lo: none) of an
+ * image of h <= 64 rows into waves -- round 5's tape rules with a window per sample; pieces[3 w + i] = piece i of wave w
+ * (k | slo << 3 | shi << 9 | a0 << 15 | 1 << 21, 0 = none; room for 6 c words), *n_waves = waves used.  tests/test_dcl_pack.py. */
+int lic360_dcl_pack_layout(int h, int c, const int *lo, const int *hi, unsigned *pieces, int *n_waves);
 /* enable > 0: the following encodes / decodes count what they execute (0: stop; < 0: leave as it is).  out (host, 2 * 12 * 64 values, may be NULL; reading clears):
  * [0][layer][group block] live (tile, group block) pairs of the encode-order launches (64 positions x the block's groups, per sample),
  * [1][layer][group] cells the decode-order launches stored.  *skip_active_out (may be NULL): 0 the codec does not skip (generic kernels or
