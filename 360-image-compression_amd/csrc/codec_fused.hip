@@ -679,7 +679,8 @@ static int dmalloc(T **p, size_t n) {
 // Pinned, host-coherent buffers + polled flags between the GPU and one host thread per image; see lic360_codec::coder_mode.
 #define HL_FB 16                               // flags: [0] tables of plane `seq` are in tab_h, [1] bitstreams of decode `gen` are in bytes_h, [2] abort,
 #define HL_MAXB 64                             //        [HL_FB + i] image i's symbols of plane `seq` are in sym_h
-#define HL_SPIN_LIMIT 400000L                  // polls of a GPU-side wait before it gives up (~1 s): a dead host thread is an error, never a hang
+#define HL_SPIN_LIMIT 2000000L                 // polls of a GPU-side wait before it gives up (~4 s: a host thread that lost its core on a busy box gets it back long before): a dead
+                                               // host thread is an error, never a hang
 struct HostLeg {
     int maxB = 0, tab_pitch = 0;
     long cap = 0, nsym = 0;
@@ -753,8 +754,12 @@ static void hl_encode_image(HostLeg *h, int i, long n, long cap) {
 static void hl_encode_all(void *ud) {                                   // (a stream callback: no HIP call in here)
     HlEncJob *j = (HlEncJob *)ud;
     std::vector<std::thread> th;
-    for (int i = 1; i < j->B; ++i) th.emplace_back(hl_encode_image, j->h, i, j->n, j->cap);
+    int started = 1;
+    try {
+        for (int i = 1; i < j->B; ++i, ++started) th.emplace_back(hl_encode_image, j->h, i, j->n, j->cap);
+    } catch (...) {}                                                    // (no more threads to be had: the rest runs here, one after the other)
     hl_encode_image(j->h, 0, j->n, j->cap);
+    for (int i = started; i < j->B; ++i) hl_encode_image(j->h, i, j->n, j->cap);
     for (std::thread &t : th) t.join();
     delete j;
 }
@@ -1130,7 +1135,14 @@ static int codec_decode_impl(void *stream, lic360_codec *c, const uint8_t *bytes
         LAUNCH_CHECK();
         std::vector<int> lens(c->P);
         for (int p = 0; p < c->P; ++p) { int st0, ln; lic360_plane_window(p, G, H, W, pih, &st0, &ln); lens[p] = ln; }
-        for (int i = 0; i < B; ++i) h->workers.emplace_back(hl_decode_worker, h, i, cap, gen, lens);
+        try {
+            for (int i = 0; i < B; ++i) h->workers.emplace_back(hl_decode_worker, h, i, cap, gen, lens);
+        } catch (...) {                                                 // (thread creation failed: release the ones that started, report)
+            hl_st(h->flags + 2, 1);
+            hl_join(h);
+            lic360_set_error("host leg of the coder: cannot start %d decode threads (lic360_codec_set_coder(codec, 0) keeps the coder on the GPU)", B);
+            return 1;
+        }
     } else {
         hipLaunchKernelGGL(k_dec_init, dim3((B + 63) / 64), dim3(64), 0, s, bytes, cap, nbytes, c->d_state, B);
         LAUNCH_CHECK();

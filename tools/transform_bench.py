@@ -71,7 +71,7 @@ def measure(batch=8, device=0, reps=3):
                          "miopen_conv_alone_ms": t_c * 1e3, "miopen_conv_with_pad_prelu_trim_add_ms": t_l * 1e3,
                          "speedup_vs_miopen_conv_alone": t_c / t_o, "speedup_vs_library_form": t_l / t_o})
     one = whole_codec(enc, dec, device)                                     # 48 images, one stream (+ the importance codec on a side stream)
-    row = whole_codec_streams(enc, dec, device, batch=144, nstreams=3)      # the bench's own batch structure: 144 images = 3 sub-batches of 48 on 3 streams
+    row = whole_codec_streams(enc, dec, device, batch=192, nstreams=3)      # the bench's own batch structure: 192 images = 3 sub-batches of 64 on 3 streams (round 6; 144 = 3 x 48 before)
     row["one_stream_48_images_mpixel_s"], row["one_stream_48_images_ms_per_image"] = one["achieved"], one["ms_per_image"]
     row["roundtrip_exact"] = bool(row["roundtrip_exact"] and one["roundtrip_exact"])
     rows.append(row)
