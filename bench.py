@@ -405,13 +405,14 @@ def run_rank(args):
 
     say("timed region done: %.1f ms per step" % (dt / args.steps * 1e3))
     extras = {}
+    ks = max(1, min(args.steps, 3))                                    # timed steps of the side figures (the headline alone runs args.steps: the default run stays within minutes)
     if not args.no_extras and B > 144 and all(sz >= 48 for sz in sizes) and ns == 3:
         # the per-GPU batch of rounds 1-5 (144 = 3 x 48 images) through the same codecs: what the larger sub-batches add
         c48, m48, l48 = [c[:48] for c in codes], [m[:48] for m in masks], [l[:48] for l in levels]
         run(c48, m48, l48)
-        dt48 = shard.timed(lambda: run(c48, m48, l48), args.steps, dev)
+        dt48 = shard.timed(lambda: run(c48, m48, l48), ks, dev)
         ok = ok and exact(c48, m48, l48)
-        extras["batch144"] = {"value": world * 144 * args.steps * PIXELS / dt48 / 1e6, "unit": "Mpixel/s", "ms_per_step": dt48 / args.steps * 1e3,
+        extras["batch144"] = {"value": world * 144 * ks * PIXELS / dt48 / 1e6, "unit": "Mpixel/s", "ms_per_step": dt48 / ks * 1e3,
                               "note": "144 images per GPU (3 sub-batches of 48), the per-GPU batch of rounds 1-5"}
     if not args.no_extras and args.masks != "iid":
         # the same step on the masks of rounds 1-5 (every map cell drawn independently): nothing for the dead-cone skip to find -- the adversarial case
@@ -421,16 +422,16 @@ def run_rank(args):
             cdi.append(torch.from_numpy(ci[o:o + sz]).to(dev)); mki.append(torch.from_numpy(mi[o:o + sz]).to(dev)); lvi.append(torch.from_numpy(li[o:o + sz]).to(dev))
             o += sz
         run(cdi, mki, lvi)
-        dti = shard.timed(lambda: run(cdi, mki, lvi), args.steps, dev)
+        dti = shard.timed(lambda: run(cdi, mki, lvi), ks, dev)
         ok = ok and exact(cdi, mki, lvi)
-        extras["iid_masks"] = {"value": world * B * args.steps * PIXELS / dti / 1e6, "unit": "Mpixel/s", "ms_per_step": dti / args.steps * 1e3,
+        extras["iid_masks"] = {"value": world * B * ks * PIXELS / dti / 1e6, "unit": "Mpixel/s", "ms_per_step": dti / ks * 1e3,
                                "note": "the timed step on i.i.d. importance maps (tests/util.py:latent, the workload of rounds 1-5)"}
         del cdi, mki, lvi
     if not args.no_extras:
         # the latent stream alone (98.6 % of the bytes, 95 % of the MACs): round 1's headline, kept for comparison
         run(codes, masks, levels, False)
-        dt_lat = shard.timed(lambda: run(codes, masks, levels, False), args.steps, dev)
-        extras["latent_stream_only"] = {"value": world * B * args.steps * PIXELS / dt_lat / 1e6, "unit": "Mpixel/s", "ms_per_step": dt_lat / args.steps * 1e3}
+        dt_lat = shard.timed(lambda: run(codes, masks, levels, False), ks, dev)
+        extras["latent_stream_only"] = {"value": world * B * ks * PIXELS / dt_lat / 1e6, "unit": "Mpixel/s", "ms_per_step": dt_lat / ks * 1e3}
         # BASELINE.json configs[3]: 64 images, image i -> rank i mod N, through the same codecs and streams
         mine = shard.shard_indices(64, rank, world)
         c4, m4, l4 = synth_latents(64, seed0=640000)
